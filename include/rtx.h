@@ -1,0 +1,185 @@
+/*
+ * rtx.h -- C-ABI of the MI355X (gfx950) render path.
+ *
+ * Drop-in boundary for ONE hot path of ChandanY1011/ray-tracing: the per-pixel render loop
+ * `render2Dantialiasing` (raytracing.cpp:719-783) together with everything it calls
+ * (`raytrace` :371-647, the intersection and vector helpers :116-366).  The reference has no
+ * plugin / FFI interface: its only seam is that function, which communicates
+ * through mutable globals (:98-113).  This header restates that seam as plain C: the globals
+ * become one `rtx_scene` view, the compile-time constants (:12, :112-113) become `rtx_params`,
+ * and the image comes back in a caller-owned buffer that the host then writes out as the
+ * reference does (:786-797).
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  No C++ or torch types cross it.
+ * All entry points return 0 on success or a negative RTX_E_* code; none of them exits, throws
+ * or prints (the reference's per-ray prints at :149 / :191 are dropped; counts go to rtx_stats).
+ * The library has NO CPU fallback: without a HIP device every compute entry point fails with
+ * RTX_E_NO_DEVICE.
+ */
+#ifndef RTX_H_
+#define RTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 0x00010000u
+
+/* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
+ * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
+
+/* raytracing.cpp:15-20  `struct vector3f` (12 B) */
+typedef struct rtx_vec3 { float x, y, z; } rtx_vec3;
+
+/* raytracing.cpp:23-28  `struct xmatrix` (48 B).  Row-vector convention: rows a,b,c are the
+ * linear part, d the translation (:171-173). */
+typedef struct rtx_xmatrix { rtx_vec3 a, b, c, d; } rtx_xmatrix;
+
+/* raytracing.cpp:31-40  `struct sphere` (120 B) */
+typedef struct rtx_sphere {
+    rtx_vec3 center;
+    int32_t  istransformed;
+    float    radius, reflectivity, transparency, refractive_index, specexpo;
+    rtx_vec3 color, speccoeff, diffcolor;
+    rtx_xmatrix mat;
+} rtx_sphere;
+
+/* raytracing.cpp:43-49  `struct plane` (40 B).  Parsed (:886-895) but never traced by the
+ * reference: accepted and ignored here too. */
+typedef struct rtx_plane {
+    rtx_vec3 normal, color;
+    float    d, reflectivity, transparency, refractive_index;
+} rtx_plane;
+
+/* raytracing.cpp:52-59  `struct triangle` (88 B) */
+typedef struct rtx_triangle {
+    rtx_vec3 u, v, w;
+    rtx_vec3 color, speccoeff, diffcolor;
+    float    reflectivity, transparency, refractive_index, specexpo;
+} rtx_triangle;
+
+/* raytracing.cpp:62-68  `struct light` (24 B) */
+typedef struct rtx_light { rtx_vec3 point, color; } rtx_light;
+
+/* The reference's globals (:98-110) as one read-only view.  The caller owns every pointer;
+ * the library copies what it needs during the call that receives the view. */
+typedef struct rtx_scene {
+    const rtx_sphere*   spheres;    int32_t nspheres;     /* :98,  :106 */
+    const rtx_triangle* triangles;  int32_t ntriangles;   /* :100, :108 */
+    const rtx_plane*    planes;     int32_t nplanes;      /* :99,  :107  (ignored, F7) */
+    const rtx_light*    lights;     int32_t nlights;      /* :102, :110 */
+    rtx_vec3 camera, vrp, vpn, up;                        /* :103  `vcs` */
+    rtx_vec3 ambient;                                     /* :104 */
+    int32_t  npolygons_ignored;  /* polygon records (:101, :910-967) the loader consumed but did
+                                    not keep: polygons are not traced yet */
+} rtx_scene;
+
+/* The reference's compile-time constants as run-time parameters, plus the band decomposition.
+ *
+ * Rows are grouped into bands of `band_rows` consecutive scanlines; band b belongs to rank
+ * (b % nranks).  A rank's framebuffer is its own rows, in increasing row order, packed.
+ * nranks = 1 (or 0) means "this call renders every row".  band_rows <= 0 selects contiguous
+ * bands, ceil(height / nranks) rows each. */
+typedef struct rtx_params {
+    int32_t  width;        /* raytracing.cpp:112 (640) */
+    int32_t  height;       /* raytracing.cpp:113 (480) */
+    int32_t  max_depth;    /* raytracing.cpp:12  MAX_depth (4): rays of generation > max_depth are never spawned */
+    int32_t  nranks;       /* number of band owners (processes / GPUs) */
+    int32_t  rank;         /* which owner this call renders for */
+    int32_t  band_rows;    /* rows per band */
+    int32_t  device;       /* HIP device ordinal; -1 = current device */
+    uint32_t flags;        /* RTX_F_* */
+    uint64_t workspace_bytes; /* cap on per-context ray-queue memory; 0 = default (8 GiB) */
+} rtx_params;
+
+#define RTX_F_NONE 0u
+
+/* Work actually done by the last render of a context (all counts are for this rank's rows,
+ * halo rows included). */
+#define RTX_MAX_LEVELS 32
+typedef struct rtx_stats {
+    uint64_t rays_primary;      /* generation-0 rays traced */
+    uint64_t rays_secondary;    /* reflection + refraction rays traced */
+    uint64_t rays_shadow;       /* shadow rays traced (one per hit per light) */
+    uint64_t hits;              /* rays that found a primitive */
+    uint64_t rays_level[RTX_MAX_LEVELS]; /* rays per generation */
+    uint64_t tests_closest;     /* ray x primitive tests executed by closest-hit (rays * nprims) */
+    uint64_t tests_shadow_max;  /* upper bound for shadow rays (no early exit): rays * nprims */
+    uint64_t singular_matrices; /* transformed spheres whose matrix has det == 0 (:148) */
+    int32_t  chunks;            /* row chunks the frame was traced in */
+    int32_t  levels;            /* generations run (max_depth + 1) */
+    float    ms_total;          /* device time of the last render, HIP events on its stream */
+    float    ms_closest;        /* (profile builds only; else 0) */
+    float    ms_shadow;
+} rtx_stats;
+
+enum {
+    RTX_OK            =  0,
+    RTX_E_INVALID_ARG = -1,
+    RTX_E_NO_DEVICE   = -2,
+    RTX_E_HIP         = -3,
+    RTX_E_OOM         = -4,
+    RTX_E_IO          = -5,
+    RTX_E_TOO_LARGE   = -6
+};
+
+/* ---- library ---------------------------------------------------------------------------- */
+uint32_t    rtx_abi_version(void);
+const char* rtx_strerror(int code);
+/* Number of HIP devices visible, 0 if none (never an error code). */
+int         rtx_device_count(void);
+/* Last HIP error string seen by the calling thread ("" if none). */
+const char* rtx_last_hip_error(void);
+
+/* ---- one-shot drop-in: replaces raytracing.cpp:725-783 --------------------------------------
+ * Renders the rows `params` selects (all of them for nranks <= 1) with 3x3 antialiasing and
+ * the reference's 8-bit quantisation (:792-794) into rgb_out[rows * width * 3].  With
+ * params->nranks <= 1 and ngpus > 1 the frame is split over the first `ngpus` devices of this
+ * process (one host thread each) and assembled in rgb_out. */
+int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
+                    uint8_t* rgb_out, rtx_stats* stats_or_null);
+
+/* Same rows, but the pre-antialiasing 1-sample-per-pixel float image: what the reference's
+ * render2d() (:801-833) holds in image[][] before quantisation.  out[rows * width * 3]. */
+int rtx_render_f32(const rtx_scene* scene, const rtx_params* params,
+                   float* rgb_out, rtx_stats* stats_or_null);
+
+/* ---- resident context: scene + all work buffers live in HBM across frames ------------------
+ * (what a serving loop or the benchmark uses; create allocates, render does not). */
+typedef struct rtx_context rtx_context;
+
+int  rtx_context_create(const rtx_scene* scene, const rtx_params* params, rtx_context** out);
+void rtx_context_destroy(rtx_context* ctx);
+/* Rows this context renders (its bands), and their global row numbers (rows_out may be NULL). */
+int  rtx_context_rows(const rtx_context* ctx, int32_t* rows_out, int32_t capacity);
+/* Enqueue one full render of the context's rows on `hip_stream` (a hipStream_t, NULL = default
+ * stream).  Asynchronous.  If d_rgb8_out is non-NULL it is a DEVICE pointer to rows*width*3
+ * bytes that receives the quantised framebuffer (e.g. the send buffer of an RCCL gather);
+ * otherwise the context's own device framebuffer is used. */
+int  rtx_context_render(rtx_context* ctx, void* hip_stream, uint8_t* d_rgb8_out);
+/* Wait for the stream, then copy out.  host buffers: rows*width*3 elements. */
+int  rtx_context_read_rgb8(rtx_context* ctx, uint8_t* host_rgb8_out);
+int  rtx_context_read_f32(rtx_context* ctx, float* host_rgb_f32_out);
+int  rtx_context_stats(rtx_context* ctx, rtx_stats* stats_out);
+
+/* ---- band arithmetic (pure host functions; no device needed) -------------------------------- */
+/* Number of rows rank `rank` owns; fills rows_out[0..n) with their global indices if non-NULL. */
+int  rtx_band_rows(int32_t height, int32_t nranks, int32_t rank, int32_t band_rows,
+                   int32_t* rows_out, int32_t capacity);
+
+/* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
+/* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),
+ * records zero-filled before parsing.  Polygon records are consumed and dropped.
+ * The returned scene owns its arrays; release with rtx_scene_free. */
+int  rtx_scene_load(const char* path, rtx_scene** out);
+void rtx_scene_free(rtx_scene* scene);
+/* "P6\n%i %i 255\n" + bytes, as raytracing.cpp:786-797. */
+int  rtx_write_ppm(const char* path, int32_t width, int32_t height, const uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H_ */

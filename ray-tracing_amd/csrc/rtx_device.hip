@@ -1,0 +1,824 @@
+// rtx_device.hip -- gfx950 kernels and the resident render context behind include/rtx.h.
+//
+// The reference's recursive raytrace() (raytracing.cpp:371-647) becomes an iterative wavefront
+// over ray generations ("levels"):
+//
+//   raygen                       level-0 rays, one thread per pixel            (:753-759)
+//   for level k = 0 .. max_depth
+//     closest_hit(k)             brute force over all spheres, then triangles   (:382-419)
+//     hit_setup(k)               hit point / normal, spawn reflect + refract
+//                                rays into level k+1 (wave-ballot compaction)   (:436-526)
+//     shadow_any(k)              one any-hit ray per (hit, light)               (:560-589)
+//   for level k = max_depth .. 0
+//     unwind(k)                  children first, then lights in file order,
+//                                then ambient: the reference's add order        (:446-646)
+//   aa_quantise                  3x3 weighted filter + 8-bit quantisation       (:738-783,:792-794)
+//
+// Queue sizes live in device memory; every launch covers the queue's capacity and threads past
+// the live count exit, so a frame is enqueued without a single host round trip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_math.hip.h"
+#include "rtx_pack.h"
+
+namespace rtx {
+
+static thread_local std::string g_last_hip_error;
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_last_hip_error = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            return (e_ == hipErrorOutOfMemory) ? RTX_E_OOM : RTX_E_HIP;                       \
+        }                                                                                     \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr float kBias = 1e-4f;       // raytracing.cpp:447
+constexpr float kMaxT = 1e8f;        // raytracing.cpp:10 (float nearest = Max_t)
+constexpr int kTFlag = 1 << 30;      // the reference's `transformed` flag, carried in the prim word
+
+// ------------------------------------------------------------------------------------------------
+// device-side views
+// ------------------------------------------------------------------------------------------------
+struct SceneDev {
+    int ns, nt, nl;
+    const float4* sph_hot;        // [ns]  cx cy cz r^2
+    const int* sph_xf;            // [ns]
+    const rtx_xmatrix* sph_im;    // [ns]  precomputed inverseMatrix(mat)
+    const rtx_sphere* sph;        // [ns]
+    const float4* tri_hot;        // [nt*5]
+    const rtx_triangle* tri;      // [nt]
+    const rtx_light* lights;      // [nl]
+    F3 ambient;
+};
+
+struct CamDev {
+    F3 ncrossv, up, vpn, camera, orig;
+    const float* imagex;  // [width]
+    const float* imagey;  // [height]
+};
+
+// One ray generation.  Rays are SoA (coalesced: lane i touches element i of each array).
+struct LevelDev {
+    int cap;
+    float *ox, *oy, *oz, *dx, *dy, *dz;  // rays
+    float* t;                            // nearest
+    int* prim;                           // -1 miss | sphere i | ns + triangle i, | kTFlag
+    float* val;                          // [cap*3] colour returned by raytrace() for this ray
+    // hit records ("nodes"), compacted
+    int* n_ray;                          // owning ray slot
+    float *n_nx, *n_ny, *n_nz;           // shading normal (after the :458-461 flip)
+    float *n_px, *n_py, *n_pz;           // intpoint
+    int *n_crefl, *n_crefr;              // child ray slots in the next level, -1 = none
+    float* n_fres;                       // fresnel (:465)
+    unsigned char* lit;                  // [nl*cap] 1 = light reaches the hit (not in shadow)
+};
+
+__device__ __forceinline__ TriRec load_tri(const float4* hot, int i)
+{
+    const float4* p = hot + (size_t)i * 5;
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriRec T;
+    T.nx = a.x; T.ny = a.y; T.nz = a.z; T.d = a.w;
+    T.vx = b.x; T.vy = b.y; T.vz = b.z; T.area = b.w;
+    T.wx = c.x; T.wy = c.y; T.wz = c.z; T.v1x = c.w;
+    T.v1y = d.x; T.v1z = d.y; T.v2x = d.z; T.v2y = d.w;
+    T.v2z = e.x; T.ex = e.y; T.ey = e.z; T.ez = e.w;
+    return T;
+}
+
+// Slot allocation for a compacted queue: one atomicAdd per wavefront (64-bit ballot + mbcnt
+// prefix), so queue order is wave-granular and the counter sees 1/64th of the traffic.
+__device__ __forceinline__ int wave_alloc(bool want, int* counter)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return -1;
+    unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
+    int prefix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return want ? base + prefix : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 ray generation (raytracing.cpp:753-759); origin is one constant (:735-737) but is stored
+// per ray so that every level has the same layout.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_raygen(LevelDev L, CamDev C, const int* trace_rows, int ti0,
+                                                   int nrows, int width, int* nrays)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    int n = nrows * width;
+    if (i == 0) *nrays = n;
+    if (i >= n) return;
+    int r = i / width, x = i - r * width;
+    int y = trace_rows[ti0 + r];
+    float imagex = C.imagex[x], imagey = C.imagey[y];
+    float a = imagex - C.camera.x, b = imagey - C.camera.y, c = -C.camera.z;
+    F3 d;
+    d.x = a * C.ncrossv.x + b * C.up.x + c * C.vpn.x;
+    d.y = a * C.ncrossv.y + b * C.up.y + c * C.vpn.y;
+    d.z = a * C.ncrossv.z + b * C.up.z + c * C.vpn.z;
+    d = normalized(d);
+    L.ox[i] = C.orig.x; L.oy[i] = C.orig.y; L.oz[i] = C.orig.z;
+    L.dx[i] = d.x; L.dy[i] = d.y; L.dz[i] = d.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 closest hit (raytracing.cpp:382-419).  One ray per lane; the primitive index is
+// wave-uniform, so primitive records arrive through scalar loads and sit in SGPRs.
+// Spheres first, in file order, strict `<` (lowest index wins ties); then triangles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, const int* nrays)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *nrays) return;
+    F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
+    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    F3 nd = normalized(d);  // :390 for untransformed spheres: same input every iteration
+    float nearest = kMaxT;
+    int best = -1;
+    int tflag = 0;
+    for (int s = 0; s < S.ns; s++) {
+        float4 h = S.sph_hot[s];
+        F3 to = o, td = nd;
+        int xf = S.sph_xf[s];
+        if (xf) {  // wave-uniform branch
+            const rtx_xmatrix& im = S.sph_im[s];
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (sphere_test(to, td, h.x, h.y, h.z, h.w, t)) {
+            if (t < nearest) {
+                nearest = t;
+                best = s;
+                if (xf) tflag = kTFlag;  // sticky (:396-399)
+            }
+        }
+    }
+    for (int k = 0; k < S.nt; k++) {
+        TriRec T = load_tri(S.tri_hot, k);
+        float t, vd;
+        if (triangle_test(o, d, T, t, vd)) {
+            if (t < nearest) {
+                nearest = t;
+                best = S.ns + k;
+                tflag = 0;  // :416
+            }
+        }
+    }
+    L.t[i] = nearest;
+    L.prim[i] = (best < 0) ? -1 : (best | tflag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 hit set-up and spawn (raytracing.cpp:436-526)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelDev N, const int* nrays,
+                                                  int* nnodes, int* nnext, int spawn)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    bool live = i < *nrays;
+    int pw = live ? L.prim[i] : -1;
+    bool hit = pw >= 0;
+    if (live && !hit) {  // :436-438: background, no ambient
+        L.val[3 * i + 0] = 0.4f; L.val[3 * i + 1] = 0.4f; L.val[3 * i + 2] = 0.4f;
+    }
+    int node = wave_alloc(hit, nnodes);
+    bool want_refl = false, want_refr = false;
+    F3 o = f3(0, 0, 0), d = o, normal = o, ip = o, rd = o;
+    float fres = 0.0f, fratio = 0.0f, eta = 1.0f;
+    if (hit) {
+        o = f3(L.ox[i], L.oy[i], L.oz[i]);
+        d = f3(L.dx[i], L.dy[i], L.dz[i]);
+        float nearest = L.t[i];
+        bool tflag = (pw & kTFlag) != 0;
+        int prim = pw & ~kTFlag;
+        bool is_sphere = prim < S.ns;
+        float reflectivity, transparency, ri;
+        if (is_sphere) {
+            const rtx_sphere& s = S.sph[prim];
+            const rtx_xmatrix& im = S.sph_im[prim];
+            // recompute the winner's object-space normal (:229-231, :395-398)
+            F3 to = o, td = d;
+            if (s.istransformed) { to = inv_apply(o, im); td = inv_apply(d, im); }
+            td = normalized(td);
+            normal = sphere_normal(to, td, nearest, s);
+            if (s.istransformed) normal = inv_apply_normal(normal, im);
+            reflectivity = s.reflectivity; transparency = s.transparency; ri = s.refractive_index;
+        } else {
+            const float4* p = S.tri_hot + (size_t)(prim - S.ns) * 5;
+            float4 q0 = p[0];
+            float vd = q0.x * d.x + q0.y * d.y + q0.z * d.z;
+            normal = (vd > 0.0f) ? f3(-q0.x, -q0.y, -q0.z) : f3(q0.x, q0.y, q0.z);  // :343-347
+            const rtx_triangle& t = S.tri[prim - S.ns];
+            reflectivity = t.reflectivity; transparency = t.transparency; ri = t.refractive_index;
+        }
+        ip = f3(o.x + nearest * d.x, o.y + nearest * d.y, o.z + nearest * d.z);  // :440
+        if (tflag) ip = fwd_apply(ip, S.sph[prim].mat);                          // :441-444
+        normal = normalized(normal);                                             // :445
+        if (spawn) {  // depth < MAX_depth (:449)
+            bool insphere = false;
+            rd = d;
+            if (is_sphere) {
+                if (tflag) rd = inv_apply(d, S.sph_im[prim]);  // :452-455
+                rd = normalized(rd);
+                if (dot3(normal, rd) > 0.0f) {                 // :458-461
+                    normal = f3(-normal.x, -normal.y, -normal.z);
+                    insphere = true;
+                }
+            }
+            want_refl = reflectivity > 0.0f;
+            want_refr = transparency > 0.0f;
+            if (want_refl || want_refr) {
+                fratio = -(dot3(rd, normal));
+                fres = fresnel_term(fratio);
+                eta = ri;
+                if (insphere) eta = (float)(1.0 / (double)ri);  // :477-479 (spheres only)
+            }
+        }
+        L.n_ray[node] = i;
+        L.n_nx[node] = normal.x; L.n_ny[node] = normal.y; L.n_nz[node] = normal.z;
+        L.n_px[node] = ip.x; L.n_py[node] = ip.y; L.n_pz[node] = ip.z;
+        L.n_fres[node] = fres;
+    }
+    if (!spawn) {
+        if (hit) { L.n_crefl[node] = -1; L.n_crefr[node] = -1; }
+        return;
+    }
+    int crefl = wave_alloc(want_refl, nnext);
+    int crefr = wave_alloc(want_refr, nnext);
+    if (hit) { L.n_crefl[node] = crefl; L.n_crefr[node] = crefr; }
+    if (want_refl) {  // :464-468
+        F3 r = f3(rd.x + 2.0f * fratio * normal.x, rd.y + 2.0f * fratio * normal.y, rd.z + 2.0f * fratio * normal.z);
+        r = normalized(r);
+        N.ox[crefl] = ip.x + normal.x * kBias; N.oy[crefl] = ip.y + normal.y * kBias; N.oz[crefl] = ip.z + normal.z * kBias;
+        N.dx[crefl] = r.x; N.dy[crefl] = r.y; N.dz[crefl] = r.z;
+    }
+    if (want_refr) {  // :476-488
+        float raydotn = fratio;
+        float k = (float)(1.0 - (double)(eta * eta) * (1.0 - (double)(raydotn * raydotn)));
+        float coef = eta * raydotn - sqrtf(k);  // NaN when k < 0: the child then misses everything
+        F3 r = f3(rd.x * eta + normal.x * coef, rd.y * eta + normal.y * coef, rd.z * eta + normal.z * coef);
+        r = normalized(r);
+        N.ox[crefr] = ip.x - normal.x * kBias; N.oy[crefr] = ip.y - normal.y * kBias; N.oz[crefr] = ip.z - normal.z * kBias;
+        N.dx[crefr] = r.x; N.dy[crefr] = r.y; N.dz[crefr] = r.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 shadow any-hit (raytracing.cpp:560-589): one thread per (hit, light); blockIdx.y = light.
+// No distance limit: any primitive at t >= 0 along the ray blocks the light.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shadow(SceneDev S, LevelDev L, const int* nnodes)
+{
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *nnodes) return;
+    int li = blockIdx.y;
+    F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
+    F3 n = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
+    const rtx_light& Lt = S.lights[li];
+    F3 ld = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));  // :561-562
+    F3 o = f3(ip.x + n.x * kBias, ip.y + n.y * kBias, ip.z + n.z * kBias);            // :568
+    F3 nld = normalized(ld);  // :575 for untransformed spheres
+    bool shadow = false;
+    for (int s = 0; s < S.ns && !shadow; s++) {
+        float4 h = S.sph_hot[s];
+        F3 td = nld;
+        if (S.sph_xf[s]) td = normalized(inv_apply(ld, S.sph_im[s]));  // :572-575; origin NOT transformed
+        float t;
+        shadow = sphere_test(o, td, h.x, h.y, h.z, h.w, t);
+    }
+    for (int k = 0; k < S.nt && !shadow; k++) {
+        TriRec T = load_tri(S.tri_hot, k);
+        float t, vd;
+        shadow = triangle_test(o, ld, T, t, vd);
+    }
+    L.lit[(size_t)li * L.cap + j] = shadow ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 unwind (raytracing.cpp:446, :470-472, :490-492, :590-646): colour of one hit from its
+// children's colours, in the reference's add order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_unwind(SceneDev S, LevelDev L, LevelDev N, const int* nnodes)
+{
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= *nnodes) return;
+    int i = L.n_ray[j];
+    int pw = L.prim[i];
+    int prim = pw & ~kTFlag;
+    bool is_sphere = prim < S.ns;
+    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    F3 n = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
+    F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
+    F3 color, spec, diff;
+    float transparency, specexpo;
+    bool xf = false;
+    if (is_sphere) {
+        const rtx_sphere& s = S.sph[prim];
+        color = f3(s.color); spec = f3(s.speccoeff); diff = f3(s.diffcolor);
+        transparency = s.transparency; specexpo = s.specexpo;
+        xf = s.istransformed != 0;
+    } else {
+        const rtx_triangle& t = S.tri[prim - S.ns];
+        color = f3(t.color); spec = f3(t.speccoeff); diff = f3(t.diffcolor);
+        transparency = t.transparency; specexpo = t.specexpo;
+    }
+    F3 pix = f3(0.0f, 0.0f, 0.0f);
+    float fres = L.n_fres[j];
+    int crefl = L.n_crefl[j], crefr = L.n_crefr[j];
+    if (crefl >= 0) {  // :470-472
+        pix.x += N.val[3 * crefl + 0] * fres * color.x;
+        pix.y += N.val[3 * crefl + 1] * fres * color.y;
+        pix.z += N.val[3 * crefl + 2] * fres * color.z;
+    }
+    if (crefr >= 0) {  // :490-492: (1.0 - fresnel) makes the whole right-hand side double
+        double w = 1.0 - (double)fres;
+        pix.x = (float)((double)pix.x + (double)N.val[3 * crefr + 0] * w * (double)transparency * (double)color.x);
+        pix.y = (float)((double)pix.y + (double)N.val[3 * crefr + 1] * w * (double)transparency * (double)color.y);
+        pix.z = (float)((double)pix.z + (double)N.val[3 * crefr + 2] * w * (double)transparency * (double)color.z);
+    }
+    // view direction used by the specular term (:592-599 spheres, :619 triangles)
+    F3 vdir = d;
+    if (is_sphere) {
+        if (xf) vdir = inv_apply(d, S.sph_im[prim]);
+        vdir = normalized(vdir);
+    }
+    for (int li = 0; li < S.nl; li++) {
+        if (!L.lit[(size_t)li * L.cap + j]) continue;
+        const rtx_light& Lt = S.lights[li];
+        F3 lc = f3(Lt.color);
+        F3 ld = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));
+        float dp = dot3(n, ld);
+        float dotprod = (0.0f < dp) ? dp : 0.0f;  // std::max(float(0.0), dp): NaN -> 0
+        F3 ldir = ld;
+        if (is_sphere) {
+            if (xf) ldir = inv_apply(ld, S.sph_im[prim]);
+            ldir = normalized(ldir);
+        }
+        float ndoti2 = 2.0f * (dot3(ldir, n));
+        F3 rr = normalized(f3(ndoti2 * n.x - ldir.x, ndoti2 * n.y - ldir.y, ndoti2 * n.z - ldir.z));
+        float rdotv = -(dot3(vdir, rr));
+        float pw_ = powf_rn(rdotv, specexpo);
+        pix.x += spec.x * pw_ * lc.x;
+        pix.y += spec.y * pw_ * lc.y;
+        pix.z += spec.z * pw_ * lc.z;
+        pix.x += dotprod * diff.x * lc.x;
+        pix.y += dotprod * diff.y * lc.y;
+        pix.z += dotprod * diff.z * lc.z;
+    }
+    pix.x += S.ambient.x; pix.y += S.ambient.y; pix.z += S.ambient.z;  // :643-645
+    L.val[3 * i + 0] = pix.x; L.val[3 * i + 1] = pix.y; L.val[3 * i + 2] = pix.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 3x3 antialias + quantise (raytracing.cpp:745-780, :792-794).  The reference re-traces the
+// neighbour rays; raytrace() is a pure function of the pixel, so filtering the 1-spp image in
+// the same row-major add order is byte-identical.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_aa_quantise(const float* fimg, const int* row2ti, const int* own_rows,
+                                                        int nown, int width, int height, unsigned char* out)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nown * width) return;
+    int r = i / width, x = i - r * width;
+    int y = own_rows[r];
+    float counter = 0.0f, ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (int yv = y - 1; yv <= y + 1; yv++)
+        for (int xv = x - 1; xv <= x + 1; xv++)
+            if (xv >= 0 && yv >= 0 && xv < width && yv < height) {
+                const float* p = fimg + ((size_t)row2ti[yv] * width + xv) * 3;
+                counter = counter + 1.0f;
+                if (yv == y && xv == x) { ax += 2.0f * p[0]; ay += 2.0f * p[1]; az += 2.0f * p[2]; }
+                else { ax += p[0]; ay += p[1]; az += p[2]; }
+            }
+    float dv = counter + 1.0f;
+    ax = ax / dv; ay = ay / dv; az = az / dv;
+    out[3 * (size_t)i + 0] = quantise(ax);
+    out[3 * (size_t)i + 1] = quantise(ay);
+    out[3 * (size_t)i + 2] = quantise(az);
+}
+
+// counters of one chunk -> 64-bit frame totals
+__global__ void k_accumulate(const int* cnt, unsigned long long* totals, int levels)
+{
+    int k = threadIdx.x;
+    if (k < 2 * levels) totals[k] += (unsigned long long)cnt[k];
+}
+
+}  // namespace rtx
+
+// ================================================================================================
+// host side: resident context
+// ================================================================================================
+using namespace rtx;
+
+struct rtx_context {
+    int device = 0;
+    rtx_params params{};
+    int width = 0, height = 0, levels = 1;
+    uint64_t singular = 0;
+    int fanout = 0;
+    std::vector<int> own_rows, trace_rows, row2ti;
+    std::vector<void*> allocs;
+    SceneDev S{};
+    CamDev C{};
+    std::vector<LevelDev> L;
+    int chunk_rows = 0;
+    int* d_trace_rows = nullptr; int* d_row2ti = nullptr; int* d_own_rows = nullptr;
+    float* d_fimg = nullptr;
+    unsigned char* d_rgb8 = nullptr;
+    int* d_cnt = nullptr;                   // [2*levels]: rays per level, then nodes per level
+    unsigned long long* d_totals = nullptr; // [2*levels]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool rendered = false;
+    int nchunks = 0;
+
+    template <typename T> int dalloc(T** p, size_t n)
+    {
+        void* q = nullptr;
+        if (n == 0) n = 1;
+        HIPCHK(hipMalloc(&q, n * sizeof(T)));
+        allocs.push_back(q);
+        *p = (T*)q;
+        return RTX_OK;
+    }
+    template <typename T> int upload(T** p, const std::vector<T>& v)
+    {
+        int rc = dalloc(p, v.size());
+        if (rc) return rc;
+        if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return RTX_OK;
+    }
+};
+
+static int validate(const rtx_scene* sc, const rtx_params* p)
+{
+    if (!sc || !p) return RTX_E_INVALID_ARG;
+    if (p->width <= 0 || p->height <= 0 || p->max_depth < 0) return RTX_E_INVALID_ARG;
+    if (p->max_depth + 1 > RTX_MAX_LEVELS) return RTX_E_TOO_LARGE;
+    if ((int64_t)p->width * p->height > (int64_t)1 << 30) return RTX_E_TOO_LARGE;
+    if (sc->nspheres < 0 || sc->ntriangles < 0 || sc->nlights < 0) return RTX_E_INVALID_ARG;
+    if ((sc->nspheres && !sc->spheres) || (sc->ntriangles && !sc->triangles) || (sc->nlights && !sc->lights))
+        return RTX_E_INVALID_ARG;
+    if ((int64_t)sc->nspheres + sc->ntriangles >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
+    if (sc->nlights > 65535) return RTX_E_TOO_LARGE;  // gridDim.y
+    int nr = p->nranks <= 1 ? 1 : p->nranks;
+    int rk = p->nranks <= 1 ? 0 : p->rank;
+    if (rk < 0 || rk >= nr) return RTX_E_INVALID_ARG;
+    return RTX_OK;
+}
+
+static int context_create_impl(const rtx_scene* scene, const rtx_params* params, rtx_context* c)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RTX_E_NO_DEVICE;
+    int dev = params->device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(dev));
+    c->device = dev;
+    c->params = *params;
+    c->width = params->width;
+    c->height = params->height;
+    const int W = c->width, H = c->height;
+
+    // rows: owned rows, plus a one-row halo either side so the 3x3 filter needs no exchange
+    int nown = rtx_band_rows(H, params->nranks, params->rank, params->band_rows, nullptr, 0);
+    if (nown < 0) return nown;
+    c->own_rows.resize(nown);
+    if (nown) rtx_band_rows(H, params->nranks, params->rank, params->band_rows, c->own_rows.data(), nown);
+    c->row2ti.assign(H, -1);
+    std::vector<char> need(H, 0);
+    for (int y : c->own_rows)
+        for (int yy = y - 1; yy <= y + 1; yy++)
+            if (yy >= 0 && yy < H) need[yy] = 1;
+    for (int y = 0; y < H; y++)
+        if (need[y]) { c->row2ti[y] = (int)c->trace_rows.size(); c->trace_rows.push_back(y); }
+    const int ntrace = (int)c->trace_rows.size();
+
+    PackedScene P;
+    pack_scene(*scene, W, H, P);
+    c->singular = P.singular;
+    c->fanout = P.max_fanout;
+    c->levels = (P.max_fanout == 0) ? 1 : params->max_depth + 1;
+    const int levels = c->levels;
+
+    // scene upload
+    int rc;
+    {
+        float4* hot = nullptr;
+        static_assert(sizeof(SphHot) == sizeof(float4), "sphere hot record is one float4");
+        static_assert(sizeof(TriHot) == 5 * sizeof(float4), "triangle hot record is five float4");
+        if ((rc = c->dalloc(&hot, P.sph_hot.size()))) return rc;
+        if (!P.sph_hot.empty()) HIPCHK(hipMemcpy(hot, P.sph_hot.data(), P.sph_hot.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->S.sph_hot = hot;
+        float4* thot = nullptr;
+        if ((rc = c->dalloc(&thot, P.tri_hot.size() * 5))) return rc;
+        if (!P.tri_hot.empty()) HIPCHK(hipMemcpy(thot, P.tri_hot.data(), P.tri_hot.size() * sizeof(TriHot), hipMemcpyHostToDevice));
+        c->S.tri_hot = thot;
+        int* xf = nullptr; rtx_xmatrix* im = nullptr; rtx_sphere* sp = nullptr; rtx_triangle* tr = nullptr; rtx_light* lt = nullptr;
+        if ((rc = c->upload(&xf, P.sph_xf))) return rc;
+        if ((rc = c->upload(&im, P.sph_im))) return rc;
+        if ((rc = c->upload(&sp, P.sph))) return rc;
+        if ((rc = c->upload(&tr, P.tri))) return rc;
+        if ((rc = c->upload(&lt, P.lights))) return rc;
+        c->S.sph_xf = xf; c->S.sph_im = im; c->S.sph = sp; c->S.tri = tr; c->S.lights = lt;
+        c->S.ns = (int)P.sph.size(); c->S.nt = (int)P.tri.size(); c->S.nl = (int)P.lights.size();
+        c->S.ambient = {P.ambient.x, P.ambient.y, P.ambient.z};
+        float* ix = nullptr; float* iy = nullptr;
+        if ((rc = c->upload(&ix, P.imagex))) return rc;
+        if ((rc = c->upload(&iy, P.imagey))) return rc;
+        c->C.imagex = ix; c->C.imagey = iy;
+        c->C.ncrossv = {P.ncrossv.x, P.ncrossv.y, P.ncrossv.z};
+        c->C.up = {P.up.x, P.up.y, P.up.z};
+        c->C.vpn = {P.vpn.x, P.vpn.y, P.vpn.z};
+        c->C.camera = {P.camera.x, P.camera.y, P.camera.z};
+        c->C.orig = {P.orig.x, P.orig.y, P.orig.z};
+    }
+    if ((rc = c->upload(&c->d_trace_rows, c->trace_rows))) return rc;
+    if ((rc = c->upload(&c->d_row2ti, c->row2ti))) return rc;
+    if ((rc = c->upload(&c->d_own_rows, c->own_rows))) return rc;
+    if ((rc = c->dalloc(&c->d_fimg, (size_t)ntrace * W * 3))) return rc;
+    if ((rc = c->dalloc(&c->d_rgb8, (size_t)nown * W * 3))) return rc;
+    if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels))) return rc;
+    if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels))) return rc;
+
+    // chunking: level k holds at most fanout^k rays per level-0 ray
+    const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
+    double mult = 0, m = 1;
+    for (int k = 0; k < levels; k++) { mult += m; m *= (c->fanout >= 2 ? 2.0 : 1.0); }
+    uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)8 << 30);
+    double per_row = (double)W * mult * (double)slot_bytes;
+    int64_t rows = (int64_t)((double)budget / per_row);
+    if (rows < 1) rows = 1;
+    if (rows > ntrace) rows = ntrace;
+    // the deepest level's capacity must stay indexable by int
+    while (rows > 1 && (double)rows * W * (m / (c->fanout >= 2 ? 2.0 : 1.0)) > (double)((int64_t)1 << 30)) rows /= 2;
+    c->chunk_rows = (int)std::max<int64_t>(rows, 1);
+    if (ntrace == 0) c->chunk_rows = 1;
+
+    c->L.resize(levels);
+    size_t cap = (size_t)c->chunk_rows * W;
+    for (int k = 0; k < levels; k++) {
+        LevelDev& L = c->L[k];
+        if (cap > ((size_t)1 << 30)) return RTX_E_TOO_LARGE;
+        L.cap = (int)cap;
+        float** fl[] = {&L.ox, &L.oy, &L.oz, &L.dx, &L.dy, &L.dz, &L.t, &L.n_nx, &L.n_ny, &L.n_nz, &L.n_px, &L.n_py, &L.n_pz, &L.n_fres};
+        for (float** f : fl)
+            if ((rc = c->dalloc(f, cap))) return rc;
+        int** il[] = {&L.prim, &L.n_ray, &L.n_crefl, &L.n_crefr};
+        for (int** f : il)
+            if ((rc = c->dalloc(f, cap))) return rc;
+        if (k == 0) L.val = nullptr;  // level-0 colours are written straight into the float image
+        else if ((rc = c->dalloc(&L.val, cap * 3))) return rc;
+        if ((rc = c->dalloc(&L.lit, cap * (size_t)std::max(c->S.nl, 1)))) return rc;
+        if (c->fanout >= 2) cap *= 2;
+    }
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    return RTX_OK;
+}
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
+{
+    HIPCHK(hipSetDevice(c->device));
+    const int W = c->width, levels = c->levels;
+    const int ntrace = (int)c->trace_rows.size(), nown = (int)c->own_rows.size();
+    HIPCHK(hipEventRecord(c->ev0, st));
+    HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
+    int nchunks = 0;
+    for (int ti0 = 0; ti0 < ntrace; ti0 += c->chunk_rows, nchunks++) {
+        int nrows = std::min(c->chunk_rows, ntrace - ti0);
+        size_t npix = (size_t)nrows * W;
+        int* rays = c->d_cnt;
+        int* nodes = c->d_cnt + levels;
+        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * 2 * levels, st));
+        LevelDev L0 = c->L[0];
+        L0.val = c->d_fimg + (size_t)ti0 * W * 3;
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
+        size_t live_cap = npix;  // upper bound on live rays at this level
+        std::vector<size_t> bound(levels);
+        for (int k = 0; k < levels; k++) {
+            LevelDev Lk = (k == 0) ? L0 : c->L[k];
+            LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
+            bound[k] = live_cap;
+            int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
+            unsigned g = grid_for(live_cap);
+            hipLaunchKernelGGL(k_closest, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
+                               spawn ? rays + k + 1 : rays + k, spawn);
+            if (c->S.nl > 0)
+                hipLaunchKernelGGL(k_shadow, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
+            if (c->fanout >= 2) live_cap *= 2;
+        }
+        for (int k = levels - 1; k >= 0; k--) {
+            LevelDev Lk = (k == 0) ? L0 : c->L[k];
+            LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
+            hipLaunchKernelGGL(k_unwind, dim3(grid_for(bound[k])), dim3(kBlock), 0, st, c->S, Lk, Ln, nodes + k);
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
+    }
+    if (nown > 0)
+        hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
+                           c->d_own_rows, nown, W, c->height, d_out ? d_out : c->d_rgb8);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, st));
+    c->last_stream = st;
+    c->rendered = true;
+    c->nchunks = nchunks;
+    return RTX_OK;
+}
+
+extern "C" {
+
+int rtx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+const char* rtx_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int rtx_context_create(const rtx_scene* scene, const rtx_params* params, rtx_context** out)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    *out = nullptr;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    rtx_context* c = new (std::nothrow) rtx_context();
+    if (!c) return RTX_E_OOM;
+    rc = context_create_impl(scene, params, c);
+    if (rc) { rtx_context_destroy(c); return rc; }
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_context_destroy(rtx_context* c)
+{
+    if (!c) return;
+    if (!c->allocs.empty() || c->ev0 || c->ev1) {
+        (void)hipSetDevice(c->device);
+        if (c->rendered) (void)hipStreamSynchronize(c->last_stream);
+        for (void* p : c->allocs) (void)hipFree(p);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+    }
+    delete c;
+}
+
+int rtx_context_rows(const rtx_context* c, int32_t* rows_out, int32_t capacity)
+{
+    if (!c) return RTX_E_INVALID_ARG;
+    int n = (int)c->own_rows.size();
+    if (rows_out) {
+        if (capacity < n) return RTX_E_INVALID_ARG;
+        std::memcpy(rows_out, c->own_rows.data(), sizeof(int32_t) * n);
+    }
+    return n;
+}
+
+int rtx_context_render(rtx_context* c, void* hip_stream, uint8_t* d_rgb8_out)
+{
+    if (!c) return RTX_E_INVALID_ARG;
+    return context_render_impl(c, (hipStream_t)hip_stream, d_rgb8_out);
+}
+
+int rtx_context_read_rgb8(rtx_context* c, uint8_t* host)
+{
+    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    size_t n = c->own_rows.size() * (size_t)c->width * 3;
+    if (n) HIPCHK(hipMemcpy(host, c->d_rgb8, n, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_context_read_f32(rtx_context* c, float* host)
+{
+    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    size_t rowf = (size_t)c->width * 3;
+    for (size_t r = 0; r < c->own_rows.size(); r++) {
+        int ti = c->row2ti[c->own_rows[r]];
+        HIPCHK(hipMemcpy(host + r * rowf, c->d_fimg + (size_t)ti * rowf, rowf * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return RTX_OK;
+}
+
+int rtx_context_stats(rtx_context* c, rtx_stats* s)
+{
+    if (!c || !s || !c->rendered) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    std::memset(s, 0, sizeof *s);
+    std::vector<unsigned long long> t(2 * c->levels);
+    HIPCHK(hipMemcpy(t.data(), c->d_totals, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint64_t nprims = (uint64_t)c->S.ns + c->S.nt;
+    for (int k = 0; k < c->levels; k++) {
+        s->rays_level[k] = t[k];
+        if (k == 0) s->rays_primary = t[k]; else s->rays_secondary += t[k];
+        s->hits += t[c->levels + k];
+    }
+    s->rays_shadow = s->hits * (uint64_t)c->S.nl;
+    s->tests_closest = (s->rays_primary + s->rays_secondary) * nprims;
+    s->tests_shadow_max = s->rays_shadow * nprims;
+    s->singular_matrices = c->singular;
+    s->chunks = c->nchunks;
+    s->levels = c->levels;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    s->ms_total = ms;
+    return RTX_OK;
+}
+
+static int render_one(const rtx_scene* scene, const rtx_params* params, uint8_t* rgb, float* f32, rtx_stats* stats)
+{
+    rtx_context* c = nullptr;
+    int rc = rtx_context_create(scene, params, &c);
+    if (rc) return rc;
+    rc = rtx_context_render(c, nullptr, nullptr);
+    if (!rc && rgb) rc = rtx_context_read_rgb8(c, rgb);
+    if (!rc && f32) rc = rtx_context_read_f32(c, f32);
+    if (!rc && stats) rc = rtx_context_stats(c, stats);
+    rtx_context_destroy(c);
+    return rc;
+}
+
+int rtx_render_f32(const rtx_scene* scene, const rtx_params* params, float* out, rtx_stats* stats)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    return render_one(scene, params, nullptr, out, stats);
+}
+
+int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    if (params->nranks > 1 || ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
+    // In-process multi-GPU: one host thread per device, interleaved bands, each device copies
+    // its own rows to the host over its own PCIe link; rows are placed in the caller's frame.
+    int ndev = rtx_device_count();
+    if (ndev <= 0) return RTX_E_NO_DEVICE;
+    if (ngpus > ndev) ngpus = ndev;
+    std::vector<int> rcs(ngpus, 0);
+    std::vector<rtx_stats> sts(ngpus);
+    std::vector<std::thread> th;
+    const size_t rowb = (size_t)params->width * 3;
+    for (int g = 0; g < ngpus; g++)
+        th.emplace_back([&, g]() {
+            rtx_params p = *params;
+            p.nranks = ngpus; p.rank = g; p.device = g;
+            if (p.band_rows <= 0) p.band_rows = 16;
+            int n = rtx_band_rows(p.height, p.nranks, p.rank, p.band_rows, nullptr, 0);
+            if (n <= 0) { rcs[g] = n < 0 ? n : 0; std::memset(&sts[g], 0, sizeof(rtx_stats)); return; }
+            std::vector<int32_t> rows(n);
+            rtx_band_rows(p.height, p.nranks, p.rank, p.band_rows, rows.data(), n);
+            std::vector<uint8_t> tmp((size_t)n * rowb);
+            rcs[g] = render_one(scene, &p, tmp.data(), nullptr, &sts[g]);
+            if (rcs[g]) return;
+            for (int r = 0; r < n; r++) std::memcpy(out + (size_t)rows[r] * rowb, tmp.data() + (size_t)r * rowb, rowb);
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < ngpus; g++)
+        if (rcs[g]) return rcs[g];
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (int g = 0; g < ngpus; g++) {
+            const rtx_stats& s = sts[g];
+            stats->rays_primary += s.rays_primary; stats->rays_secondary += s.rays_secondary;
+            stats->rays_shadow += s.rays_shadow; stats->hits += s.hits;
+            for (int k = 0; k < RTX_MAX_LEVELS; k++) stats->rays_level[k] += s.rays_level[k];
+            stats->tests_closest += s.tests_closest; stats->tests_shadow_max += s.tests_shadow_max;
+            stats->singular_matrices = s.singular_matrices;
+            stats->chunks += s.chunks; stats->levels = std::max(stats->levels, s.levels);
+            stats->ms_total = std::max(stats->ms_total, s.ms_total);
+        }
+    }
+    return RTX_OK;
+}
+
+}  // extern "C"

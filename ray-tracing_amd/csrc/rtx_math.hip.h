@@ -1,0 +1,172 @@
+// rtx_math.hip.h -- device-side scalar math with the reference's exact IEEE-754 semantics.
+//
+// Parity contract (BASELINE.json north_star): FP contraction off in both builds.  This file is
+// compiled with -ffp-contract=off and without any fast-math flag, so every * + - / sqrt below is
+// one correctly rounded binary32 (or, where the reference promotes through a double literal,
+// binary64) operation, evaluated in the reference's order.  hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt keeps `/` and sqrtf correctly rounded and the default
+// gfx950 float mode keeps denormals, matching x86-64 SSE2.
+#ifndef RTX_MATH_HIP_H_
+#define RTX_MATH_HIP_H_
+
+#include <hip/hip_runtime.h>
+
+#include "rtx.h"
+
+namespace rtx {
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ F3 f3(const rtx_vec3& a) { return f3(a.x, a.y, a.z); }
+
+// raytracing.cpp:127-130
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// raytracing.cpp:116-125: divide only when the norm is > 0 (NaN and 0 leave v untouched)
+__device__ __forceinline__ F3 normalized(F3 v)
+{
+    float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (n > 0.0f) {
+        v.x = v.x / n;
+        v.y = v.y / n;
+        v.z = v.z / n;
+    }
+    return v;
+}
+
+// raytracing.cpp:185-187 with the inverse `im` precomputed on the host (rtx_pack.cpp).  The
+// translation row is added to directions as well as points, as the reference does.
+__device__ __forceinline__ F3 inv_apply(F3 v, const rtx_xmatrix& im)
+{
+    F3 r;
+    r.x = v.x * im.a.x + v.y * im.b.x + v.z * im.c.x + im.d.x;
+    r.y = v.x * im.a.y + v.y * im.b.y + v.z * im.c.y + im.d.y;
+    r.z = v.x * im.a.z + v.y * im.b.z + v.z * im.c.z + im.d.z;
+    return r;
+}
+
+// raytracing.cpp:189-196 (the "transpose" mode used for normals)
+__device__ __forceinline__ F3 inv_apply_normal(F3 v, const rtx_xmatrix& im)
+{
+    float val = v.x * im.d.x + v.y * im.d.y + v.z * im.d.z + 1.0f;
+    if (val == 0.0f) return v;
+    F3 r;
+    r.x = (v.x * im.a.x + v.y * im.a.y + v.z * im.a.z) / val;
+    r.y = (v.x * im.b.x + v.y * im.b.y + v.z * im.b.z) / val;
+    r.z = (v.x * im.c.x + v.y * im.c.y + v.z * im.c.z) / val;
+    return r;
+}
+
+// raytracing.cpp:169-175: the freshly written x feeds y, and x,y feed z
+__device__ __forceinline__ F3 fwd_apply(F3 v, const rtx_xmatrix& m)
+{
+    v.x = v.x * m.a.x + v.y * m.b.x + v.z * m.c.x + m.d.x;
+    v.y = v.x * m.a.y + v.y * m.b.y + v.z * m.c.y + m.d.y;
+    v.z = v.x * m.a.z + v.y * m.b.z + v.z * m.c.z + m.d.z;
+    return v;
+}
+
+// raytracing.cpp:202-228.  Returns what intersectsphere returns (true also when the discriminant
+// is NaN: every comparison is then false), t = the root the reference leaves in t0.
+__device__ __forceinline__ bool sphere_test(F3 o, F3 d, float cx, float cy, float cz, float r2, float& t)
+{
+    float X = o.x - cx, Y = o.y - cy, Z = o.z - cz;
+    float b = 2.0f * (d.x * X + d.y * Y + d.z * Z);
+    float c = X * X + Y * Y + Z * Z - r2;
+    float disc = b * b - 4.0f * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float t0 = (-b - sq) / 2.0f;
+    float t1 = (-b + sq) / 2.0f;
+    if (t0 < 0.0f && t1 < 0.0f) return false;
+    if (t0 < 0.0f) t0 = t1;
+    if (t1 > 0.0f) t0 = (t1 < t0) ? t1 : t0;  // std::min(t0, t1)
+    t = t0;
+    return true;
+}
+
+// raytracing.cpp:229-231
+__device__ __forceinline__ F3 sphere_normal(F3 o, F3 d, float t, const rtx_sphere& s)
+{
+    F3 n;
+    n.x = (o.x + d.x * t - s.center.x) / s.radius;
+    n.y = (o.y + d.y * t - s.center.y) / s.radius;
+    n.z = (o.z + d.z * t - s.center.z) / s.radius;
+    return n;
+}
+
+// Triangle hot record as packed by rtx_pack.cpp (TriHot): 5 float4.
+struct TriRec {
+    float nx, ny, nz, d;
+    float vx, vy, vz, area;
+    float wx, wy, wz, v1x;
+    float v1y, v1z, v2x, v2y;
+    float v2z, ex, ey, ez;
+};
+
+// raytracing.cpp:338-365 with the ray-independent head precomputed.  Returns what
+// intersecttriangle returns (true also on NaN); vd is handed back for the facing normal (:343-347).
+__device__ __forceinline__ bool triangle_test(F3 o, F3 dir, const TriRec& T, float& t, float& vd)
+{
+    vd = T.nx * dir.x + T.ny * dir.y + T.nz * dir.z;
+    if (vd == 0.0f) return false;
+    t = -((T.nx * o.x + T.ny * o.y + T.nz * o.z) + T.d) / vd;
+    if (t < 0.0f) return false;
+    float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+    float ax = px - T.vx, ay = py - T.vy, az = pz - T.vz;  // vec1
+    float bx = px - T.wx, by = py - T.wy, bz = pz - T.wz;  // vec2
+    // cross1 (:356), cross2 (:357), cross3 (:358), component orders as written
+    float c1x = ay * T.v1z - T.v1y * az, c1y = T.v1x * az - T.v1z * ax, c1z = T.v1y * ax - T.v1x * ay;
+    float c2x = az * T.v2y - ay * T.v2z, c2y = ax * T.v2z - az * T.v2x, c2z = ay * T.v2x - ax * T.v2y;
+    float c3x = bz * T.ey - by * T.ez, c3y = bx * T.ez - bz * T.ex, c3z = by * T.ex - bx * T.ey;
+    float areau = 0.5f * sqrtf(c2x * c2x + c2y * c2y + c2z * c2z);
+    float areav = 0.5f * sqrtf(c3x * c3x + c3y * c3y + c3z * c3z);
+    float areaw = 0.5f * sqrtf(c1x * c1x + c1y * c1y + c1z * c1z);
+    // (double)f > 0.01  <=>  f > 0.01f, because 0.01f < 0.01 < nextafterf(0.01f)
+    if (fabsf(areau + areav + areaw - T.area) > 0.01f) return false;
+    return true;
+}
+
+// x*x*x rounded once (error-free products; the tail sum is far below half an ulp), standing in
+// for glibc's pow(x, 3.0) (raytracing.cpp:465) which is correctly rounded in all but
+// vanishingly rare cases; the result is rounded to float right after (see fresnel_term).
+__device__ __forceinline__ double cube_rn(double x)
+{
+    double p = x * x;
+    double pe = __builtin_fma(x, x, -p);
+    double q = p * x;
+    double qe = __builtin_fma(p, x, -q);
+    return q + (qe + pe * x);
+}
+
+// raytracing.cpp:465 / :481 / :499 / :511:  float fresnel = 0.1*1 + 0.9*pow(1.0 - fratio, 3);
+__device__ __forceinline__ float fresnel_term(float fratio)
+{
+    double x = 1.0 - (double)fratio;
+    return (float)(0.1 + 0.9 * cube_rn(x));
+}
+
+// raytracing.cpp:606: pow(float, float) = glibc powf.  Evaluated through the double-precision
+// pow and rounded once to float: the correctly rounded binary32 power except with probability
+// ~2^-29.  glibc's powf is itself within a few hundredths of an ulp of that before rounding, so
+// the two agree except for operands whose exact power lies that close to a rounding boundary
+// (measured mismatch rate: DESIGN.md "numerics"); the north-star tolerance (+-1 LSB) covers it.
+__device__ __forceinline__ float powf_rn(float x, float y)
+{
+    return (float)pow((double)x, (double)y);
+}
+
+// raytracing.cpp:792-794: fputc(min(float(1.0), v)*255, f).  std::min(1.0f, v) is 1.0f for NaN;
+// float -> int truncates; below-range values give INT_MIN on x86-64 (low byte 0), which is also
+// what v_cvt_i32_f32 saturates to.
+__device__ __forceinline__ unsigned char quantise(float v)
+{
+    float m = (v < 1.0f) ? v : 1.0f;
+    float p = m * 255.0f;
+    int i = (p > -2147483648.0f) ? (int)p : (int)0x80000000u;
+    return (unsigned char)(i & 0xff);
+}
+
+}  // namespace rtx
+#endif

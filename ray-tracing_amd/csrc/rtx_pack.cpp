@@ -1,0 +1,126 @@
+// rtx_pack.cpp -- see rtx_pack.h.  Build with -ffp-contract=off (no FMA on the host either).
+#include "rtx_pack.h"
+
+#include <cmath>
+
+namespace rtx {
+
+namespace {
+
+inline float det3(const rtx_vec3& a, const rtx_vec3& b, const rtx_vec3& c)
+{
+    // raytracing.cpp:137-142; rows a,b,c.  `-1*a.y*(..)` is (-a.y)*(..)
+    float x = a.x * (b.y * c.z - b.z * c.y);
+    float y = (-a.y) * (b.x * c.z - b.z * c.x);
+    float z = a.z * (b.x * c.y - b.y * c.x);
+    return (x + y) + z;
+}
+
+inline void normalize(rtx_vec3& v)
+{
+    // raytracing.cpp:116-125: untouched when the norm is 0 or NaN
+    float n = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (n > 0.0f) {
+        v.x = v.x / n;
+        v.y = v.y / n;
+        v.z = v.z / n;
+    }
+}
+
+inline float dot(const rtx_vec3& a, const rtx_vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+}  // namespace
+
+rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular)
+{
+    // raytracing.cpp:144-165.  Adjugate / det with the reference's entry formulas kept as
+    // written -- including c.z, whose second product is a.y*b.z where a true cofactor has
+    // a.y*b.x (:160) -- and "singular => hand back m itself" (:148-151).
+    const rtx_vec3 &a = m.a, &b = m.b, &c = m.c, &d = m.d;
+    float det = det3(a, b, c);
+    if (singular) *singular = (det == 0);
+    if (det == 0) return m;
+    rtx_xmatrix r = m;
+    r.a.x = (b.y * c.z - b.z * c.y) / det;
+    r.a.y = (-(a.y * c.z - c.y * a.z)) / det;
+    r.a.z = (a.y * b.z - b.y * a.z) / det;
+    r.b.x = (-(b.x * c.z - c.x * b.z)) / det;
+    r.b.y = (a.x * c.z - a.z * c.x) / det;
+    r.b.z = (-(a.x * b.z - a.z * b.x)) / det;
+    r.c.x = (b.x * c.y - c.x * b.y) / det;
+    r.c.y = (-(a.x * c.y - a.y * c.x)) / det;
+    r.c.z = (a.x * b.y - a.y * b.z) / det;
+    r.d.x = (-det3(b, c, d)) / det;
+    r.d.y = det3(a, c, d) / det;
+    r.d.z = (-det3(a, b, d)) / det;
+    return r;
+}
+
+void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
+{
+    P = PackedScene();
+    int fan = 0;
+    for (int i = 0; i < sc.nspheres; i++) {
+        const rtx_sphere& s = sc.spheres[i];
+        SphHot h = { s.center.x, s.center.y, s.center.z, s.radius * s.radius };
+        P.sph_hot.push_back(h);
+        P.sph_xf.push_back(s.istransformed ? 1 : 0);
+        bool sing = false;
+        P.sph_im.push_back(inverse_matrix(s.mat, &sing));
+        if (s.istransformed && sing) P.singular++;
+        P.sph.push_back(s);
+        int f = (s.reflectivity > 0 ? 1 : 0) + (s.transparency > 0 ? 1 : 0);
+        if (f > fan) fan = f;
+    }
+    for (int i = 0; i < sc.ntriangles; i++) {
+        const rtx_triangle& t = sc.triangles[i];
+        // raytracing.cpp:330-337
+        rtx_vec3 v1 = { t.u.x - t.v.x, t.u.y - t.v.y, t.u.z - t.v.z };
+        rtx_vec3 v2 = { t.w.x - t.v.x, t.w.y - t.v.y, t.w.z - t.v.z };
+        rtx_vec3 n = { v1.y * v2.z - v2.y * v1.z, v2.x * v1.z - v1.x * v2.z, v1.x * v2.y - v2.x * v1.y };
+        // 0.5*sqrt(float) is evaluated in double by the reference and rounded back: the product
+        // with 0.5 is exact either way, so the float product is the same number.
+        float area = 0.5f * std::sqrt(dot(n, n));
+        normalize(n);
+        float d = -(dot(n, t.u));
+        rtx_vec3 e = { t.u.x - t.w.x, t.u.y - t.w.y, t.u.z - t.w.z };  // :355
+        TriHot h = { { n.x, n.y, n.z, d,
+                       t.v.x, t.v.y, t.v.z, area,
+                       t.w.x, t.w.y, t.w.z, v1.x,
+                       v1.y, v1.z, v2.x, v2.y,
+                       v2.z, e.x, e.y, e.z } };
+        P.tri_hot.push_back(h);
+        P.tri.push_back(t);
+        int f = (t.reflectivity > 0 ? 1 : 0) + (t.transparency > 0 ? 1 : 0);
+        if (f > fan) fan = f;
+    }
+    for (int i = 0; i < sc.nlights; i++) P.lights.push_back(sc.lights[i]);
+    P.max_fanout = fan;
+
+    // camera basis, raytracing.cpp:725-737
+    P.camera = sc.camera;
+    P.up = sc.up;
+    P.vpn = sc.vpn;
+    P.ambient = sc.ambient;
+    P.ncrossv.x = -(sc.vpn.y * sc.up.z - sc.vpn.z * sc.up.y);
+    P.ncrossv.y = -(sc.up.x * sc.vpn.z - sc.vpn.x * sc.up.z);
+    P.ncrossv.z = -(sc.vpn.x * sc.up.y - sc.vpn.y * sc.up.x);
+    normalize(P.ncrossv);
+    float whratio = (float)width / (float)height;
+    float dwidth = (float)(1.0 / (double)(float)width);
+    float dheight = (float)(1.0 / (double)(float)height);
+    float angleofview = (float)(1.0 / (double)std::sqrt(dot(sc.camera, sc.camera)));
+    P.orig.x = sc.camera.x * P.ncrossv.x + sc.camera.y * sc.up.x + sc.camera.z * sc.vpn.x + sc.vrp.x;
+    P.orig.y = sc.camera.x * P.ncrossv.y + sc.camera.y * sc.up.y + sc.camera.z * sc.vpn.y + sc.vrp.y;
+    P.orig.z = sc.camera.x * P.ncrossv.z + sc.camera.y * sc.up.z + sc.camera.z * sc.vpn.z + sc.vrp.z;
+    // :753-754 are double expressions stored to float; imagex depends only on the column and
+    // imagey only on the row, so two small tables reproduce them exactly.
+    P.imagex.resize(width);
+    P.imagey.resize(height);
+    for (int x = 0; x < width; x++)
+        P.imagex[x] = (float)((2 * ((x + 0.5) * (double)dwidth) - 1) * (double)angleofview * (double)whratio);
+    for (int y = 0; y < height; y++)
+        P.imagey[y] = (float)((1 - 2 * ((y + 0.5) * (double)dheight)) * (double)angleofview);
+}
+
+}  // namespace rtx

@@ -1,0 +1,52 @@
+// rtx_pack.h -- host-side packing of the reference's AoS scene (rtx_scene, include/rtx.h) into
+// the records the gfx950 kernels read, plus the ray-independent precomputation the reference
+// repeats per ray:
+//   * inverseMatrix (raytracing.cpp:144-165) once per sphere instead of on every invtransform
+//     call (:182), bugs included, in the reference's exact float expression order;
+//   * the ray-independent head of intersecttriangle (:330-337, :355): edge vectors, unit normal,
+//     plane offset, area.
+// Everything is evaluated in IEEE binary32 with contraction off, so the GPU consumes constants
+// bit-identical to what the reference recomputes per ray.
+#ifndef RTX_PACK_H_
+#define RTX_PACK_H_
+
+#include <cstdint>
+#include <vector>
+
+#include "rtx.h"
+
+namespace rtx {
+
+// 80-byte hot record of one triangle: 5 x float4, read with wave-uniform (scalar) loads.
+//   q0 = { n.x, n.y, n.z, d }            unit normal `cross` (:332,:335), d = -(cross . u) (:337)
+//   q1 = { v.x, v.y, v.z, area }         vertex v, area = 0.5*sqrt(cross.cross) (:334)
+//   q2 = { w.x, w.y, w.z, v1.x }         vertex w, v1 = u - v (:330)
+//   q3 = { v1.y, v1.z, v2.x, v2.y }      v2 = w - v (:331)
+//   q4 = { v2.z, e.x, e.y, e.z }         e = u - w = `vec3` (:355)
+struct TriHot { float q[20]; };
+
+// 16-byte hot record of one sphere: { c.x, c.y, c.z, r*r } ((s.radius)*(s.radius), :211)
+struct SphHot { float cx, cy, cz, r2; };
+
+struct PackedScene {
+    std::vector<SphHot>      sph_hot;
+    std::vector<int32_t>     sph_xf;     // istransformed (:34)
+    std::vector<rtx_xmatrix> sph_im;     // inverseMatrix(mat) for EVERY sphere (needed for the stale
+                                         // `transformed` flag quirk, :396-399, :443, :454)
+    std::vector<rtx_sphere>  sph;        // raw records (materials, centre, radius, mat)
+    std::vector<TriHot>      tri_hot;
+    std::vector<rtx_triangle> tri;
+    std::vector<rtx_light>   lights;
+    // camera (raytracing.cpp:725-737)
+    rtx_vec3 ncrossv, up, vpn, camera, orig, ambient;
+    std::vector<float> imagex;           // per column, :753 evaluated in double, stored as float
+    std::vector<float> imagey;           // per row,    :754
+    uint64_t singular = 0;               // spheres with istransformed and det == 0 (:148)
+    int max_fanout = 0;                  // max children one hit can spawn: [refl>0] + [transp>0]
+};
+
+rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular);
+void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& out);
+
+}  // namespace rtx
+#endif
