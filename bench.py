@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the render hot path on the synthetic 4K scene
+(BASELINE.json configs[3]: 3840x2160, 5,000 spheres + 5,000 triangles, 4 lights, depth 5).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A "step" is one full frame: every rank traces its scanline bands (scene and
+all ray queues already resident in HBM), then the 8-bit bands are gathered to rank 0 with an RCCL
+gather (torch.distributed, backend nccl).  The frame is FIXED as N grows (strong scaling).
+value = rays actually traced (primary + reflection/refraction + shadow) per second, whole job.
+
+The JSON line also carries
+  roofline     for the dominant kernel (the shadow any-hit or the closest-hit kernel, whichever
+               took longer): algorithmic FLOPs of the ray x primitive tests it executed
+               (20 / 65 / 76 / 13 FLOP per sphere / affine sphere / triangle /
+               early-exit triangle test, counted by the kernels' counting variants in a separate
+               untimed frame) / its average launch time, measured with HIP events on the launch
+               stream during the timed steps.  The bound is FP32 VALU, not HBM or MFMA.
+  cpu_baseline the reference renderer itself (oracle/_ref/rt_ref, compiled from the reference's
+               source in the build container) or, if that binary is absent, this repo's scalar
+               C port (oracle/), timed on ONE host core on a small image of the same scene.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_TEST = (20.0, 65.0, 76.0, 13.0)  # sphere, affine sphere, triangle, triangle early exit
+PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
+PEAK_FP32_NOFMA_TFLOPS = 78.65            # contraction is off for parity: one FLOP per lane-op
+
+
+def cpu_baseline(scene_path, scene, max_depth, seconds_target=20.0):
+    """Time the CPU path on one host core on a small image of the same scene file."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "rt_ref")
+    w, h = 32, 18
+    if os.path.exists(ref):
+        # calibrate size: tiny run first
+        def run(w, h):
+            env = dict(os.environ, RT_WIDTH=str(w), RT_HEIGHT=str(h), RT_MAX_DEPTH=str(max_depth))
+            out = os.path.join(tempfile.gettempdir(), "rtx_cpu_%d.ppm" % os.getpid())
+            t0 = time.perf_counter()
+            p = subprocess.run([ref, scene_path, out], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            os.path.exists(out) and os.remove(out)
+            cnt = dict(tok.split("=") for tok in p.stderr.decode().split() if "=" in tok)
+            return int(cnt.get("trace", 0)) + int(cnt.get("shadow", 0)), dt
+        rays, dt = run(16, 9)
+        scale = max(1.0, (seconds_target / max(dt, 1e-3)) ** 0.5)
+        w, h = int(16 * scale), int(9 * scale)
+        w, h = min(w, 96), min(h, 54)
+        rays, dt = run(w, h)
+        return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="reference",
+                    sample="oracle/_ref/rt_ref (the reference's own source, g++ -O2 -ffp-contract=off), same scene file, "
+                           "%dx%d image incl. its 9x antialias re-tracing, %d rays in %.1f s" % (w, h, rays, dt))
+    import oracle_lib as O
+    t0 = time.perf_counter()
+    _, cnt = O.render_rgb8(scene, w, h, max_depth, literal_9x=True)
+    dt = time.perf_counter() - t0
+    rays = cnt.trace_calls + cnt.shadow_rays
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
+                sample="oracle/rt_oracle.c scalar port, same scene file, %dx%d image incl. 9x antialias re-tracing, "
+                       "%d rays in %.1f s" % (w, h, rays, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c5"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--band-rows", type=int, default=30)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-count", action="store_true", help="skip the untimed test-counting frame")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rtxamd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = rt.scenegen.WORKLOADS[args.workload]
+    W = args.width or wl["width"]
+    H = args.height or wl["height"]
+    md = wl["max_depth"]
+    scene_path = os.path.join(tempfile.gettempdir(), "rtx_bench_%s_%d.txt" % (args.workload, os.getpid()))
+    wl["writer"](scene_path)
+    scene = rt.load_scene(scene_path)
+
+    def make_ctx(flags):
+        p = rt.Params.make(W, H, md, nranks=world, rank=rank, band_rows=args.band_rows if world > 1 else 0,
+                           device=local_rank, flags=flags)
+        return rt.Context(scene, p)
+
+    ctx = make_ctx(rt.host.F_TIME_KERNELS)
+    nrows = len(ctx.rows)
+    stream = torch.cuda.current_stream().cuda_stream
+    band = torch.empty(nrows * W * 3, dtype=torch.uint8, device=dev)
+    if world > 1:
+        # equal-sized gather slots: pad every rank's band to the largest band
+        rows_all = [len(rt.band_rows(H, world, r, args.band_rows)) for r in range(world)]
+        slot = max(rows_all) * W * 3
+        send = torch.zeros(slot, dtype=torch.uint8, device=dev)
+        recv = [torch.empty(slot, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        if world > 1:
+            ctx.render(stream, send.data_ptr())     # the band lands directly in the gather's send buffer
+            dist.gather(send, recv, dst=0)          # RCCL over xGMI: the only cross-device step
+        else:
+            ctx.render(stream, band.data_ptr())
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()  # last frame: ray counts and per-kernel HIP-event times
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st.rays_primary), float(st.rays_secondary), float(st.rays_shadow)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    rays_frame = float(rays.sum().item())
+    value = rays_frame * args.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5" if args.workload == "c4"
+                      else "Mrays/sec (primary+secondary+shadow rays traced) at 8K depth 8",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"] if not (args.width or args.height) else wl["name"] + " [resized %dx%d]" % (W, H),
+                       "width": W, "height": H, "max_depth": md, "spheres": scene.view.nspheres,
+                       "triangles": scene.view.ntriangles, "lights": scene.view.nlights,
+                       "parallelism": "scanline bands of %d rows, round-robin over %d GPU(s), RCCL gather of rgb8" % (args.band_rows, world)
+                                      if world > 1 else "1 GPU, whole frame",
+                       "rays_per_frame": {"primary": float(rays[0].item()), "secondary": float(rays[1].item()),
+                                          "shadow": float(rays[2].item())}},
+        }
+
+    # ---- roofline of the dominant kernel (rank 0's share of the frame) ----
+    if rank == 0:
+        dom = "shadow" if st.ms_shadow >= st.ms_closest else "closest"
+        ms_dom = st.ms_shadow if dom == "shadow" else st.ms_closest
+        n_dom = st.launches_shadow if dom == "shadow" else st.launches_closest
+        roof = {"bound": "valu-fp32", "kernel": "k_shadow" if dom == "shadow" else "k_closest", "achieved": None,
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "peak_no_fma": PEAK_FP32_NOFMA_TFLOPS, "frac_no_fma": None,
+                "launches_per_frame": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
+                "ms_closest_per_frame": st.ms_closest, "ms_shadow_per_frame": st.ms_shadow, "ms_frame": st.ms_total}
+        if not args.no_count:
+            cctx = make_ctx(rt.host.F_COUNT_TESTS)
+            cctx.render(stream, None)
+            cst = cctx.stats()
+            kinds = cst.tests_shadow_kind if dom == "shadow" else cst.tests_closest_kind
+            flops = sum(float(kinds[k]) * FLOP_PER_TEST[k] for k in range(4))
+            ach = flops / (ms_dom * 1e-3) / 1e12
+            roof.update(achieved=ach, frac=ach / PEAK_FP32_TFLOPS, frac_no_fma=ach / PEAK_FP32_NOFMA_TFLOPS,
+                        flops_per_frame=flops, tests_per_frame=[float(k) for k in kinds])
+            cctx.close()
+        out["roofline"] = roof
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene_path, scene, md)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    scene.close()
+    try:
+        os.remove(scene_path)
+    except OSError:
+        pass
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,10 @@ typedef struct rtx_params {
     uint64_t workspace_bytes; /* cap on per-context ray-queue memory; 0 = default (8 GiB) */
 } rtx_params;
 
-#define RTX_F_NONE 0u
+#define RTX_F_NONE          0u
+#define RTX_F_TIME_KERNELS  1u  /* HIP events around every closest-hit and shadow launch -> rtx_stats.ms_closest/ms_shadow */
+#define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
+                                   exact ray x primitive tests executed, by kind -> rtx_stats.tests_*_kind */
 
 /* Work actually done by the last render of a context (all counts are for this rank's rows,
  * halo rows included). */
@@ -108,12 +111,18 @@ typedef struct rtx_stats {
     uint64_t rays_level[RTX_MAX_LEVELS]; /* rays per generation */
     uint64_t tests_closest;     /* ray x primitive tests executed by closest-hit (rays * nprims) */
     uint64_t tests_shadow_max;  /* upper bound for shadow rays (no early exit): rays * nprims */
+    /* RTX_F_COUNT_TESTS only: tests executed by kind {sphere, affine sphere, triangle full path,
+     * triangle leaving at vd == 0 or t < 0}; the shadow counts reflect the any-hit early exit */
+    uint64_t tests_closest_kind[4];
+    uint64_t tests_shadow_kind[4];
     uint64_t singular_matrices; /* transformed spheres whose matrix has det == 0 (:148) */
     int32_t  chunks;            /* row chunks the frame was traced in */
     int32_t  levels;            /* generations run (max_depth + 1) */
     float    ms_total;          /* device time of the last render, HIP events on its stream */
-    float    ms_closest;        /* (profile builds only; else 0) */
-    float    ms_shadow;
+    float    ms_closest;        /* RTX_F_TIME_KERNELS only: summed device time of the closest-hit launches */
+    float    ms_shadow;         /*                          ... of the shadow any-hit launches */
+    int32_t  launches_closest;  /* launches behind ms_closest / ms_shadow */
+    int32_t  launches_shadow;
 } rtx_stats;
 
 enum {

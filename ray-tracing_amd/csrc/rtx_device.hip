@@ -113,6 +113,17 @@ __device__ __forceinline__ int wave_alloc(bool want, int* counter)
     return want ? base + prefix : -1;
 }
 
+// Test counters (RTX_F_COUNT_TESTS): per-lane tallies, summed over the wave, one atomic per wave
+// and kind.  kind: 0 sphere, 1 affine sphere, 2 triangle full path, 3 triangle early exit.
+__device__ __forceinline__ void flush_counts(const unsigned int (&n)[4], unsigned long long* dst)
+{
+    for (int k = 0; k < 4; k++) {
+        unsigned int v = n[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 ray generation (raytracing.cpp:753-759); origin is one constant (:735-737) but is stored
 // per ray so that every level has the same layout.
@@ -142,10 +153,14 @@ __global__ __launch_bounds__(kBlock) void k_raygen(LevelDev L, CamDev C, const i
 // wave-uniform, so primitive records arrive through scalar loads and sit in SGPRs.
 // Spheres first, in file order, strict `<` (lowest index wins ties); then triangles.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, const int* nrays)
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, const int* nrays, unsigned long long* tests)
 {
     int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= *nrays) return;
+    bool live = i < *nrays;
+    if (!COUNT && !live) return;
+    unsigned int cnt[4] = {0, 0, 0, 0};
+    if (live) {
     F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
     F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
     F3 nd = normalized(d);  // :390 for untransformed spheres: same input every iteration
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
             td = normalized(inv_apply(d, im));
         }
         float t;
+        if (COUNT) cnt[xf ? 1 : 0]++;
         if (sphere_test(to, td, h.x, h.y, h.z, h.w, t)) {
             if (t < nearest) {
                 nearest = t;
@@ -172,8 +188,10 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
     }
     for (int k = 0; k < S.nt; k++) {
         TriRec T = load_tri(S.tri_hot, k);
-        float t, vd;
-        if (triangle_test(o, d, T, t, vd)) {
+        float t = 0.0f, vd;
+        bool h = triangle_test(o, d, T, t, vd);
+        if (COUNT) cnt[(vd == 0.0f || t < 0.0f) ? 3 : 2]++;
+        if (h) {
             if (t < nearest) {
                 nearest = t;
                 best = S.ns + k;
@@ -183,6 +201,8 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
     }
     L.t[i] = nearest;
     L.prim[i] = (best < 0) ? -1 : (best | tflag);
+    }
+    if (COUNT) flush_counts(cnt, tests);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,10 +304,14 @@ __global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelD
 // K4 shadow any-hit (raytracing.cpp:560-589): one thread per (hit, light); blockIdx.y = light.
 // No distance limit: any primitive at t >= 0 along the ray blocks the light.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shadow(SceneDev S, LevelDev L, const int* nnodes)
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow(SceneDev S, LevelDev L, const int* nnodes, unsigned long long* tests)
 {
     int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= *nnodes) return;
+    bool live = j < *nnodes;
+    if (!COUNT && !live) return;
+    unsigned int cnt[4] = {0, 0, 0, 0};
+    if (live) {
     int li = blockIdx.y;
     F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
     F3 n = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
@@ -301,14 +325,18 @@ __global__ __launch_bounds__(kBlock) void k_shadow(SceneDev S, LevelDev L, const
         F3 td = nld;
         if (S.sph_xf[s]) td = normalized(inv_apply(ld, S.sph_im[s]));  // :572-575; origin NOT transformed
         float t;
+        if (COUNT) cnt[S.sph_xf[s] ? 1 : 0]++;
         shadow = sphere_test(o, td, h.x, h.y, h.z, h.w, t);
     }
     for (int k = 0; k < S.nt && !shadow; k++) {
         TriRec T = load_tri(S.tri_hot, k);
-        float t, vd;
+        float t = 0.0f, vd;
         shadow = triangle_test(o, ld, T, t, vd);
+        if (COUNT) cnt[(vd == 0.0f || t < 0.0f) ? 3 : 2]++;
     }
     L.lit[(size_t)li * L.cap + j] = shadow ? 0 : 1;
+    }
+    if (COUNT) flush_counts(cnt, tests);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,7 +473,10 @@ struct rtx_context {
     unsigned char* d_rgb8 = nullptr;
     int* d_cnt = nullptr;                   // [2*levels]: rays per level, then nodes per level
     unsigned long long* d_totals = nullptr; // [2*levels]
+    unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
+    std::vector<int> kev_kind;              // 0 closest, 1 shadow, per pair used by the last render
     hipStream_t last_stream = nullptr;
     bool rendered = false;
     int nchunks = 0;
@@ -559,6 +590,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->dalloc(&c->d_rgb8, (size_t)nown * W * 3))) return rc;
     if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels))) return rc;
     if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels))) return rc;
+    if ((rc = c->dalloc(&c->d_tests, (size_t)8))) return rc;
 
     // chunking: level k holds at most fanout^k rays per level-0 ray
     const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
@@ -593,6 +625,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     }
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
+    if (params->flags & RTX_F_TIME_KERNELS) {
+        int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
+        c->kev.resize((size_t)nchunks * levels * 2 * 2);
+        for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
+    }
     return RTX_OK;
 }
 
@@ -605,6 +642,11 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     const int ntrace = (int)c->trace_rows.size(), nown = (int)c->own_rows.size();
     HIPCHK(hipEventRecord(c->ev0, st));
     HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
+    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 8, st));
+    const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
+    const bool timek = !c->kev.empty();
+    size_t kev_used = 0;
+    c->kev_kind.clear();
     int nchunks = 0;
     for (int ti0 = 0; ti0 < ntrace; ti0 += c->chunk_rows, nchunks++) {
         int nrows = std::min(c->chunk_rows, ntrace - ti0);
@@ -623,11 +665,18 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             bound[k] = live_cap;
             int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             unsigned g = grid_for(live_cap);
-            hipLaunchKernelGGL(k_closest, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
+            if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
+            else hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
+            if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
-            if (c->S.nl > 0)
-                hipLaunchKernelGGL(k_shadow, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
+            if (c->S.nl > 0) {
+                if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
+                if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
+                if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
+            }
             if (c->fanout >= 2) live_cap *= 2;
         }
         for (int k = levels - 1; k >= 0; k--) {
@@ -676,12 +725,13 @@ int rtx_context_create(const rtx_scene* scene, const rtx_params* params, rtx_con
 void rtx_context_destroy(rtx_context* c)
 {
     if (!c) return;
-    if (!c->allocs.empty() || c->ev0 || c->ev1) {
+    if (!c->allocs.empty() || c->ev0 || c->ev1 || !c->kev.empty()) {
         (void)hipSetDevice(c->device);
         if (c->rendered) (void)hipStreamSynchronize(c->last_stream);
         for (void* p : c->allocs) (void)hipFree(p);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
+        for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
     }
     delete c;
 }
@@ -749,6 +799,15 @@ int rtx_context_stats(rtx_context* c, rtx_stats* s)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     s->ms_total = ms;
+    unsigned long long tk[8];
+    HIPCHK(hipMemcpy(tk, c->d_tests, sizeof tk, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = tk[k]; s->tests_shadow_kind[k] = tk[4 + k]; }
+    for (size_t e = 0; e < c->kev_kind.size(); e++) {
+        float m = 0;
+        HIPCHK(hipEventElapsedTime(&m, c->kev[2 * e], c->kev[2 * e + 1]));
+        if (c->kev_kind[e] == 0) { s->ms_closest += m; s->launches_closest++; }
+        else { s->ms_shadow += m; s->launches_shadow++; }
+    }
     return RTX_OK;
 }
 

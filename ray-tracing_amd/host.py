@@ -8,6 +8,8 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "librtx.so")
 RTX_MAX_LEVELS = 32
+F_TIME_KERNELS = 1
+F_COUNT_TESTS = 2
 
 
 class RtxError(RuntimeError):
@@ -64,8 +66,8 @@ class Params(C.Structure):
 
     @classmethod
     def make(cls, width=640, height=480, max_depth=4, nranks=1, rank=0, band_rows=0, device=-1,
-             workspace_bytes=0):
-        return cls(width, height, max_depth, nranks, rank, band_rows, device, 0, workspace_bytes)
+             workspace_bytes=0, flags=0):
+        return cls(width, height, max_depth, nranks, rank, band_rows, device, flags, workspace_bytes)
 
 
 class Stats(C.Structure):
@@ -73,8 +75,10 @@ class Stats(C.Structure):
                 ("rays_shadow", C.c_uint64), ("hits", C.c_uint64),
                 ("rays_level", C.c_uint64 * RTX_MAX_LEVELS),
                 ("tests_closest", C.c_uint64), ("tests_shadow_max", C.c_uint64),
+                ("tests_closest_kind", C.c_uint64 * 4), ("tests_shadow_kind", C.c_uint64 * 4),
                 ("singular_matrices", C.c_uint64), ("chunks", C.c_int32), ("levels", C.c_int32),
-                ("ms_total", C.c_float), ("ms_closest", C.c_float), ("ms_shadow", C.c_float)]
+                ("ms_total", C.c_float), ("ms_closest", C.c_float), ("ms_shadow", C.c_float),
+                ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32)]
 
     @property
     def rays_total(self):
