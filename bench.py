@@ -117,20 +117,17 @@ def main():
     ctx = make_ctx(rt.host.F_TIME_KERNELS)
     nrows = len(ctx.rows)
     stream = torch.cuda.current_stream().cuda_stream
-    band = torch.empty(nrows * W * 3, dtype=torch.uint8, device=dev)
-    if world > 1:
-        # equal-sized gather slots: pad every rank's band to the largest band
-        rows_all = [len(rt.band_rows(H, world, r, args.band_rows)) for r in range(world)]
-        slot = max(rows_all) * W * 3
-        send = torch.zeros(slot, dtype=torch.uint8, device=dev)
-        recv = [torch.empty(slot, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    import importlib
+    bands = importlib.import_module("rtxamd_pkg.bands")
+    bg = bands.BandGather(W, H, args.band_rows if world > 1 else 0, world, rank, dev)
+    assert len(bg.my_rows) == nrows
 
     def step():
+        ctx.render(stream, bg.send.data_ptr())      # the band lands directly in the gather's send buffer
         if world > 1:
-            ctx.render(stream, send.data_ptr())     # the band lands directly in the gather's send buffer
-            dist.gather(send, recv, dst=0)          # RCCL over xGMI: the only cross-device step
-        else:
-            ctx.render(stream, band.data_ptr())
+            bg.gather()                             # RCCL over xGMI: the only cross-device step
+            if rank == 0:
+                bg.assemble()
 
     def sync():
         if world > 1:

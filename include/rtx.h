@@ -97,6 +97,8 @@ typedef struct rtx_params {
 
 #define RTX_F_NONE          0u
 #define RTX_F_TIME_KERNELS  1u  /* HIP events around every closest-hit and shadow launch -> rtx_stats.ms_closest/ms_shadow */
+#define RTX_F_EXACT_ONLY    4u  /* skip the bounding-sphere filter: run the reference's exact test on every
+                                   (ray, primitive) pair.  Must give the identical image; used to check that. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
                                    exact ray x primitive tests executed, by kind -> rtx_stats.tests_*_kind */
 
@@ -178,6 +180,13 @@ int  rtx_context_stats(rtx_context* ctx, rtx_stats* stats_out);
 /* Number of rows rank `rank` owns; fills rows_out[0..n) with their global indices if non-NULL. */
 int  rtx_band_rows(int32_t height, int32_t nranks, int32_t rank, int32_t band_rows,
                    int32_t* rows_out, int32_t capacity);
+
+/* ---- diagnostics (pure host function; no counterpart in the reference) ------------------------
+ * The conservative bounding spheres the intersection kernels filter with, one { c.x, c.y, c.z,
+ * -R^2 } record per primitive (spheres first, then triangles), and the origin guard beyond which
+ * a ray bypasses the filter.  out4 holds 4 * (nspheres + ntriangles) floats.  Lets the CPU test
+ * suite prove the filter never rejects a pair the reference's test accepts. */
+int  rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out);
 
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),

@@ -446,3 +446,32 @@ int orc_render_rgb8(const rtx_scene* sc, int width, int height, int max_depth,
         }
     return 0;
 }
+
+/* Test helper: for every (ray, primitive) pair, does the reference's intersection routine return
+ * true?  Spheres follow the closest-hit call pattern (rt.cpp:385-391: inverse-transformed origin
+ * and direction for affine spheres, direction normalised); triangles rt.cpp:409.
+ * accept[ray * (ns + nt) + prim] = 0/1.  shadow != 0 uses the shadow-ray call pattern instead
+ * (rt.cpp:571-576: only the direction is inverse-transformed). */
+void orc_accept_matrix(const rtx_scene* sc, int nrays, const float* o, const float* d, int shadow, unsigned char* accept)
+{
+    int np = sc->nspheres + sc->ntriangles;
+    for (int r = 0; r < nrays; r++) {
+        V ro = mkv(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
+        V rd = mkv(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
+        for (int i = 0; i < sc->nspheres; i++) {
+            V nt, to = ro, td = rd;
+            float t0 = MAX_T, t1 = MAX_T;
+            if (sc->spheres[i].istransformed) {
+                if (!shadow) to = orc_invtransform(ro, sc->spheres[i].mat, 0);
+                td = orc_invtransform(rd, sc->spheres[i].mat, 0);
+            }
+            orc_normalize(&td);
+            accept[(size_t)r * np + i] = (unsigned char)orc_intersect_sphere(to, td, &sc->spheres[i], &nt, &t0, &t1);
+        }
+        for (int i = 0; i < sc->ntriangles; i++) {
+            V nt;
+            float t = MAX_T;
+            accept[(size_t)r * np + sc->nspheres + i] = (unsigned char)orc_intersect_triangle(ro, rd, &sc->triangles[i], &nt, &t);
+        }
+    }
+}

@@ -48,4 +48,7 @@ int orc_render_rgb8(const rtx_scene* sc, int width, int height, int max_depth,
 /* The AA filter + quantiser alone on a full 1-spp float image (rt.cpp:738-783, :792-794). */
 void orc_filter_quantise(const float* img, int width, int height, unsigned char* out);
 
+/* test helper, see rt_oracle.c */
+void orc_accept_matrix(const rtx_scene* sc, int nrays, const float* o, const float* d, int shadow, unsigned char* accept);
+
 #endif

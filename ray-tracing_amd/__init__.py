@@ -8,8 +8,8 @@ scene generator (``scenegen``).  There is no Python or CPU fallback for the rend
 The directory name ``ray-tracing_amd`` is not a Python identifier; import it through the
 repo-root shim ``rtxamd`` (``import rtxamd as rt``).
 """
-from . import host, scenegen  # noqa: F401
+from . import host, scenegen  # noqa: F401  (bands imports torch: import it explicitly)
 from .host import (  # noqa: F401
-    Context, Params, RtxError, Scene, Stats, band_rows, device_count, lib, load_scene,
+    Context, Params, RtxError, Scene, Stats, band_rows, device_count, lib, load_scene, filter_records,
     render_f32, render_rgb8, write_ppm,
 )

@@ -46,6 +46,7 @@ static thread_local std::string g_last_hip_error;
 constexpr int kBlock = 256;
 constexpr float kBias = 1e-4f;       // raytracing.cpp:447
 constexpr float kMaxT = 1e8f;        // raytracing.cpp:10 (float nearest = Max_t)
+constexpr int kRaysPerLane = 2;      // rays per lane in the filtered intersection kernels
 constexpr int kTFlag = 1 << 30;      // the reference's `transformed` flag, carried in the prim word
 
 // ------------------------------------------------------------------------------------------------
@@ -61,6 +62,9 @@ struct SceneDev {
     const rtx_triangle* tri;      // [nt]
     const rtx_light* lights;      // [nl]
     F3 ambient;
+    const float4* bounds;         // [ns+nt] filter records { c, -R^2 } (rtx_bounds.cpp)
+    const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern
+    float guard;                  // |origin component| beyond this: the ray bypasses the filter
 };
 
 struct CamDev {
@@ -203,6 +207,256 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
     L.prim[i] = (best < 0) ? -1 : (best | tflag);
     }
     if (COUNT) flush_counts(cnt, tests);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Filtered intersection kernels (the default hot path).
+//
+// Every (ray, primitive) pair first takes an 11-instruction FMA test of the ray's line against a
+// conservative bounding sphere of the primitive (rtx_bounds.cpp proves it never rejects a pair
+// the reference's test accepts); only survivors run the exact contraction-free test above.
+// Bounding-sphere records are staged through LDS in tiles of kTile primitives and read back
+// with broadcast ds_read_b128 (all lanes, same address): primitive operands then sit in VGPRs,
+// which on gfx950 issue at twice the rate of SGPR / constant-bus operands (tools/ubench_valu2).
+// The sign bits of F over a group of kGroup primitives are AND-ed (v_and_b32, full rate) and
+// tested once per group, instead of one half-rate v_cmp per primitive.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTile = 1024;   // primitives per LDS tile (16 KiB)
+constexpr int kGroup = 8;     // primitives per sign-AND group
+
+__device__ __forceinline__ float filt(F3 fo, F3 fd, float4 b)
+{
+    float X = fo.x - b.x, Y = fo.y - b.y, Z = fo.z - b.z;
+    float bh = fd.z * Z;
+    bh = __builtin_fmaf(fd.y, Y, bh);
+    bh = __builtin_fmaf(fd.x, X, bh);
+    float cc = __builtin_fmaf(Z, Z, b.w);
+    cc = __builtin_fmaf(Y, Y, cc);
+    cc = __builtin_fmaf(X, X, cc);
+    return __builtin_fmaf(bh, bh, -cc);
+}
+
+__device__ __forceinline__ bool finite3(F3 v)
+{
+    return (fabsf(v.x) <= 3.0e38f) && (fabsf(v.y) <= 3.0e38f) && (fabsf(v.z) <= 3.0e38f);
+}
+__device__ __forceinline__ bool tiny_comp(float c) { return c != 0.0f && fabsf(c) < 1e-10f; }
+
+// A ray the filter's error analysis does not cover: it skips the filter and takes the exact test
+// against every primitive (rtx_bounds.cpp, "abnormal" lanes).
+__device__ __forceinline__ bool ray_abnormal(F3 o, F3 d, F3 nd, float guard)
+{
+    bool ok = finite3(o) && finite3(d) && finite3(nd);
+    float n2 = nd.x * nd.x + nd.y * nd.y + nd.z * nd.z;
+    ok = ok && (fabsf(n2 - 1.0f) <= 1e-3f);
+    ok = ok && (fabsf(d.x - nd.x) <= 1e-5f) && (fabsf(d.y - nd.y) <= 1e-5f) && (fabsf(d.z - nd.z) <= 1e-5f);
+    ok = ok && !(tiny_comp(d.x) || tiny_comp(d.y) || tiny_comp(d.z) || tiny_comp(nd.x) || tiny_comp(nd.y) || tiny_comp(nd.z));
+    ok = ok && (fabsf(o.x) <= guard) && (fabsf(o.y) <= guard) && (fabsf(o.z) <= guard);
+    return !ok;
+}
+
+constexpr float kDirScale = 1.0f + 1.0f / 262144.0f;  // (1 + 2^-18), see rtx_bounds.cpp
+
+// Block-cooperative staging of one tile of filter records; the tail of the last group is padded
+// with records no ray can pass (R^2 = -inf).
+__device__ __forceinline__ int stage_tile(float4* tile, const float4* bounds, int t0, int nprim)
+{
+    int cnt = min(kTile, nprim - t0);
+    for (int j = threadIdx.x; j < cnt; j += kBlock) tile[j] = bounds[t0 + j];
+    int padded = (cnt + kGroup - 1) / kGroup * kGroup;
+    for (int j = cnt + threadIdx.x; j < padded; j += kBlock) tile[j] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+    return cnt;
+}
+
+struct HitAcc { float nearest; int best; int tflag; };
+
+// exact closest-hit update for primitive k (wave-uniform), raytracing.cpp:385-403 / :407-418
+__device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3 d, F3 nd, HitAcc& h)
+{
+    if (k < S.ns) {
+        float4 hh = S.sph_hot[k];
+        int xf = S.sph_xf[k];
+        F3 to = o, td = nd;
+        if (xf) {
+            const rtx_xmatrix& im = S.sph_im[k];
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) h.tflag = kTFlag; }
+        }
+    } else {
+        TriRec T = load_tri(S.tri_hot, k - S.ns);
+        float t, vd;
+        if (triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
+{
+    __shared__ float4 tile[kTile];
+    const int n = *nrays;
+    const int base = blockIdx.x * (kBlock * R);
+    if (base >= n) return;  // block-uniform
+    F3 o[R], d[R], nd[R], fo[R], fd[R];
+    bool live[R], abn[R];
+    HitAcc h[R];
+    unsigned accinit[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int i = base + r * kBlock + threadIdx.x;
+        live[r] = i < n;
+        int ii = live[r] ? i : 0;
+        o[r] = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
+        d[r] = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
+        nd[r] = normalized(d[r]);
+        abn[r] = ray_abnormal(o[r], d[r], nd[r], S.guard);
+        bool use = live[r] && !abn[r];
+        // lanes that must never pass look at the scene from 1e18 away with a null direction
+        fo[r] = use ? o[r] : f3(1e18f, 0.0f, 0.0f);
+        fd[r] = use ? f3(nd[r].x * kDirScale, nd[r].y * kDirScale, nd[r].z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+        accinit[r] = (live[r] && abn[r]) ? 0u : 0xFFFFFFFFu;  // abnormal lanes always take the exact path
+        asm volatile("" : "+v"(accinit[r]));                  // keep it a plain v_and operand (no v_cndmask)
+        h[r].nearest = kMaxT; h[r].best = -1; h[r].tflag = 0;
+    }
+    const int nprim = S.ns + S.nt;
+    for (int t0 = 0; t0 < nprim; t0 += kTile) {
+        __syncthreads();
+        int cnt = stage_tile(tile, S.bounds, t0, nprim);
+        __syncthreads();
+        for (int g = 0; g < cnt; g += kGroup) {
+            unsigned acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = accinit[r];
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) {
+                float4 b = tile[g + u];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] &= __float_as_uint(filt(fo[r], fd[r], b));
+            }
+            unsigned any = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < R; r++) any &= acc[r];
+            if ((int)any >= 0) {  // some F in this group is not negative for this lane
+                int gend = min(kGroup, cnt - g);
+                for (int u = 0; u < gend; u++) {
+                    float4 b = tile[g + u];
+                    int k = t0 + g + u;
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (live[r] && (abn[r] || !(filt(fo[r], fd[r], b) < 0.0f))) exact_closest(S, k, o[r], d[r], nd[r], h[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int i = base + r * kBlock + threadIdx.x;
+        if (live[r]) {
+            L.t[i] = h[r].nearest;
+            L.prim[i] = (h[r].best < 0) ? -1 : (h[r].best | h[r].tflag);
+        }
+    }
+}
+
+// exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
+__device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld, F3 nld)
+{
+    if (k < S.ns) {
+        float4 hh = S.sph_hot[k];
+        F3 td = nld;
+        if (S.sph_xf[k]) td = normalized(inv_apply(ld, S.sph_im[k]));
+        float t;
+        return sphere_test(o, td, hh.x, hh.y, hh.z, hh.w, t);
+    }
+    TriRec T = load_tri(S.tri_hot, k - S.ns);
+    float t, vd;
+    return triangle_test(o, ld, T, t, vd);
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_shadow_f(SceneDev S, LevelDev L, const int* nnodes)
+{
+    __shared__ float4 tile[kTile];
+    const int n = *nnodes;
+    const int base = blockIdx.x * (kBlock * R);
+    if (base >= n) return;  // block-uniform
+    const int li = blockIdx.y;
+    const rtx_light& Lt = S.lights[li];
+    F3 o[R], ld[R], nld[R], fo[R], fd[R];
+    bool live[R], abn[R], done[R];
+    unsigned accinit[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int j = base + r * kBlock + threadIdx.x;
+        live[r] = j < n;
+        int jj = live[r] ? j : 0;
+        F3 ip = f3(L.n_px[jj], L.n_py[jj], L.n_pz[jj]);
+        F3 nn = f3(L.n_nx[jj], L.n_ny[jj], L.n_nz[jj]);
+        ld[r] = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));
+        o[r] = f3(ip.x + nn.x * kBias, ip.y + nn.y * kBias, ip.z + nn.z * kBias);
+        nld[r] = normalized(ld[r]);
+        abn[r] = ray_abnormal(o[r], ld[r], nld[r], S.guard);
+        bool use = live[r] && !abn[r];
+        fo[r] = use ? o[r] : f3(1e18f, 0.0f, 0.0f);
+        fd[r] = use ? f3(nld[r].x * kDirScale, nld[r].y * kDirScale, nld[r].z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+        accinit[r] = (live[r] && abn[r]) ? 0u : 0xFFFFFFFFu;
+        asm volatile("" : "+v"(accinit[r]));
+        done[r] = !live[r];
+    }
+    const int nprim = S.ns + S.nt;
+    for (int t0 = 0; t0 < nprim; t0 += kTile) {
+        bool alldone = true;
+#pragma unroll
+        for (int r = 0; r < R; r++) alldone = alldone && done[r];
+        if (__syncthreads_and(alldone)) break;  // every ray of the block is in shadow
+        int cnt = stage_tile(tile, S.bounds_shadow, t0, nprim);
+        __syncthreads();
+        if (__all(alldone)) continue;  // this wave is finished; it only keeps the barriers company
+        for (int g = 0; g < cnt; g += kGroup) {
+            unsigned acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = accinit[r];
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) {
+                float4 b = tile[g + u];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] &= __float_as_uint(filt(fo[r], fd[r], b));
+            }
+            unsigned any = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < R; r++) any &= acc[r];
+            if ((int)any >= 0) {
+                int gend = min(kGroup, cnt - g);
+                for (int u = 0; u < gend; u++) {
+                    float4 b = tile[g + u];
+                    int k = t0 + g + u;
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (!done[r] && (abn[r] || !(filt(fo[r], fd[r], b) < 0.0f))) {
+                            if (exact_any(S, k, o[r], ld[r], nld[r])) {
+                                done[r] = true;  // in shadow: stop passing the filter from here on
+                                fo[r] = f3(1e18f, 0.0f, 0.0f);
+                                fd[r] = f3(0.0f, 0.0f, 0.0f);
+                                accinit[r] = 0xFFFFFFFFu;
+                                asm volatile("" : "+v"(accinit[r]));
+                            }
+                        }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int j = base + r * kBlock + threadIdx.x;
+        // done && live  <=>  some primitive blocks the light
+        if (live[r]) L.lit[(size_t)li * L.cap + j] = done[r] ? 0 : 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,6 +827,16 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->S.sph_xf = xf; c->S.sph_im = im; c->S.sph = sp; c->S.tri = tr; c->S.lights = lt;
         c->S.ns = (int)P.sph.size(); c->S.nt = (int)P.tri.size(); c->S.nl = (int)P.lights.size();
         c->S.ambient = {P.ambient.x, P.ambient.y, P.ambient.z};
+        static_assert(sizeof(BoundSphere) == sizeof(float4), "filter record is one float4");
+        float4* bnd = nullptr;
+        if ((rc = c->dalloc(&bnd, P.bounds.size()))) return rc;
+        if (!P.bounds.empty()) HIPCHK(hipMemcpy(bnd, P.bounds.data(), P.bounds.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->S.bounds = bnd;
+        float4* bnds = nullptr;
+        if ((rc = c->dalloc(&bnds, P.bounds_shadow.size()))) return rc;
+        if (!P.bounds_shadow.empty()) HIPCHK(hipMemcpy(bnds, P.bounds_shadow.data(), P.bounds_shadow.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->S.bounds_shadow = bnds;
+        c->S.guard = P.guard;
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
         if ((rc = c->upload(&iy, P.imagey))) return rc;
@@ -644,6 +908,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
     HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 8, st));
     const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
+    const bool exact_only = (c->params.flags & RTX_F_EXACT_ONLY) != 0;
     const bool timek = !c->kev.empty();
     size_t kev_used = 0;
     c->kev_kind.clear();
@@ -667,14 +932,16 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             unsigned g = grid_for(live_cap);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
+            else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
+            else hipLaunchKernelGGL(k_closest_f<kRaysPerLane>, dim3((g + kRaysPerLane - 1) / kRaysPerLane), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
             if (c->S.nl > 0) {
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
                 if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
+                else if (exact_only) hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
+                else hipLaunchKernelGGL(k_shadow_f<kRaysPerLane>, dim3((g + kRaysPerLane - 1) / kRaysPerLane, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             }
             if (c->fanout >= 2) live_cap *= 2;

@@ -2,6 +2,7 @@
 #include "rtx_pack.h"
 
 #include <cmath>
+#include <limits>
 
 namespace rtx {
 
@@ -97,6 +98,29 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
     for (int i = 0; i < sc.nlights; i++) P.lights.push_back(sc.lights[i]);
     P.max_fanout = fan;
 
+    // filter records.  guard = 16 x the extent of everything finite in the scene.
+    double ext = 1.0;
+    auto grow = [&](double v) { if (std::isfinite(v) && std::fabs(v) < 1e30 && std::fabs(v) > ext) ext = std::fabs(v); };
+    for (const rtx_sphere& s : P.sph) {
+        double r = std::fabs((double)s.radius);
+        grow(std::fabs(s.center.x) + r); grow(std::fabs(s.center.y) + r); grow(std::fabs(s.center.z) + r);
+    }
+    for (const rtx_triangle& t : P.tri)
+        for (const rtx_vec3* v : {&t.u, &t.v, &t.w}) { grow(v->x); grow(v->y); grow(v->z); }
+    for (const rtx_light& l : P.lights) { grow(l.point.x); grow(l.point.y); grow(l.point.z); }
+    grow(sc.camera.x); grow(sc.camera.y); grow(sc.camera.z);
+    grow(sc.vrp.x); grow(sc.vrp.y); grow(sc.vrp.z);
+    double guard = 16.0 * ext;
+    P.guard = (float)guard;
+    guard = (double)P.guard * 1.0001;
+    for (size_t i = 0; i < P.sph.size(); i++)
+        P.bounds.push_back(P.sph[i].istransformed ? bound_sphere_affine(P.sph[i], P.sph_im[i], guard)
+                                                  : bound_sphere_plain(P.sph[i]));
+    for (size_t i = 0; i < P.tri.size(); i++) P.bounds.push_back(bound_sphere_triangle(P.tri[i], guard));
+    P.bounds_shadow = P.bounds;
+    for (size_t i = 0; i < P.sph.size(); i++)
+        if (P.sph[i].istransformed) P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+
     // camera basis, raytracing.cpp:725-737
     P.camera = sc.camera;
     P.up = sc.up;
@@ -124,3 +148,17 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
 }
 
 }  // namespace rtx
+
+extern "C" int rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out)
+{
+    if (!scene || !out4) return RTX_E_INVALID_ARG;
+    if ((scene->nspheres && !scene->spheres) || (scene->ntriangles && !scene->triangles)) return RTX_E_INVALID_ARG;
+    rtx::PackedScene P;
+    rtx::pack_scene(*scene, 1, 1, P);
+    for (size_t i = 0; i < P.bounds.size(); i++) {
+        out4[4 * i + 0] = P.bounds[i].cx; out4[4 * i + 1] = P.bounds[i].cy;
+        out4[4 * i + 2] = P.bounds[i].cz; out4[4 * i + 3] = P.bounds[i].neg_r2;
+    }
+    if (guard_out) *guard_out = P.guard;
+    return RTX_OK;
+}

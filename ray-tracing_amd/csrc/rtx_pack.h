@@ -28,7 +28,19 @@ struct TriHot { float q[20]; };
 // 16-byte hot record of one sphere: { c.x, c.y, c.z, r*r } ((s.radius)*(s.radius), :211)
 struct SphHot { float cx, cy, cz, r2; };
 
+// 16-byte filter record of one primitive (spheres first, then triangles, file order):
+// conservative bounding sphere { c.x, c.y, c.z, -R^2 } (rtx_bounds.cpp); -R^2 = -inf: always passes.
+struct BoundSphere { float cx, cy, cz, neg_r2; };
+
+BoundSphere bound_sphere_plain(const rtx_sphere& s);
+BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, double guard);
+BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard);
+
 struct PackedScene {
+    std::vector<BoundSphere> bounds;     // [nspheres + ntriangles], closest-hit call pattern
+    std::vector<BoundSphere> bounds_shadow; // same for shadow rays: affine spheres always pass there, because
+                                         // the reference transforms only the direction, not the origin (:571-576)
+    float guard = 1.0f;                  // rays with an origin component beyond this bypass the filter
     std::vector<SphHot>      sph_hot;
     std::vector<int32_t>     sph_xf;     // istransformed (:34)
     std::vector<rtx_xmatrix> sph_im;     // inverseMatrix(mat) for EVERY sphere (needed for the stale

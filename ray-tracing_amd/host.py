@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_DIR, "librtx.so")
 RTX_MAX_LEVELS = 32
 F_TIME_KERNELS = 1
 F_COUNT_TESTS = 2
+F_EXACT_ONLY = 4
 
 
 class RtxError(RuntimeError):
@@ -104,6 +105,7 @@ SYMBOLS = {
     "rtx_context_read_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtx_context_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtx_band_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.POINTER(C.c_float)]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
     "rtx_write_ppm": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -200,6 +202,14 @@ def render_f32(scene, params):
     st = Stats()
     _check(lib().rtx_render_f32(scene.ptr, C.byref(params), out.ctypes.data, C.byref(st)), "rtx_render_f32")
     return out, st
+
+
+def filter_records(scene):
+    """(records[nprims,4], guard): the kernels' conservative bounding spheres (rtx_filter_records)."""
+    out = np.zeros((scene.nprims, 4), dtype=np.float32)
+    g = C.c_float()
+    _check(lib().rtx_filter_records(scene.ptr, out.ctypes.data, C.byref(g)), "rtx_filter_records")
+    return out, g.value
 
 
 def write_ppm(path, rgb):

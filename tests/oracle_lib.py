@@ -44,6 +44,8 @@ def lib():
         L.orc_intersect_triangle.restype = C.c_int
         L.orc_intersect_triangle.argtypes = [rt.host.Vec3, rt.host.Vec3, C.POINTER(rt.host.Triangle),
                                              C.POINTER(rt.host.Vec3), C.POINTER(C.c_float)]
+        L.orc_accept_matrix.restype = None
+        L.orc_accept_matrix.argtypes = [SV, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -70,6 +72,15 @@ def filter_quantise(img):
     img = np.ascontiguousarray(img, dtype=np.float32)
     out = np.zeros((h, w, 3), dtype=np.uint8)
     lib().orc_filter_quantise(img.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
+def accept_matrix(scene, o, d, shadow=False):
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    n = o.shape[0]
+    out = np.zeros((n, scene.nprims), dtype=np.uint8)
+    lib().orc_accept_matrix(scene.ptr, n, o.ctypes.data, d.ctypes.data, int(shadow), out.ctypes.data)
     return out
 
 

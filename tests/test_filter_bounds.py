@@ -1,0 +1,125 @@
+"""The bounding-sphere filter of the intersection kernels (rtx_bounds.cpp + filt() in
+rtx_device.hip) must never reject a (ray, primitive) pair the reference's own test accepts.
+The kernel's binary32 FMA arithmetic is emulated here with numpy (float64 product + sum rounded
+to float32) on the records the library exports, and compared with the oracle's exact tests on
+rays aimed at, around and away from every primitive."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+f32 = np.float32
+
+
+def fma(a, b, c):
+    with np.errstate(all="ignore"):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+
+def filter_pass(rec, o, d):
+    with np.errstate(all="ignore"):
+        n = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f32)).astype(f32)
+        nd = np.where(n[:, None] > 0, (d / n[:, None]).astype(f32), d)
+        fd = (nd * f32(1.0 + 1.0 / 262144.0)).astype(f32)
+        P = np.ones((o.shape[0], rec.shape[0]), dtype=bool)
+        for k in range(rec.shape[0]):
+            X = (o[:, 0] - rec[k, 0]).astype(f32)
+            Y = (o[:, 1] - rec[k, 1]).astype(f32)
+            Z = (o[:, 2] - rec[k, 2]).astype(f32)
+            bh = (fd[:, 2] * Z).astype(f32)
+            bh = fma(fd[:, 1], Y, bh)
+            bh = fma(fd[:, 0], X, bh)
+            cc = fma(Z, Z, np.full_like(Z, rec[k, 3]))
+            cc = fma(Y, Y, cc)
+            cc = fma(X, X, cc)
+            P[:, k] = ~(fma(bh, bh, -cc) < 0)
+    return P
+
+
+def aimed_rays(sc, rng, n_per_prim):
+    """Rays through points on / near every primitive, from origins near and far."""
+    v = sc.view
+    targets = []
+    for i in range(v.nspheres):
+        s = v.spheres[i]
+        c = np.array([s.center.x, s.center.y, s.center.z])
+        u = rng.normal(size=(n_per_prim, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        rad = abs(s.radius) * rng.choice([0.0, 0.5, 0.999, 1.0, 1.001, 1.5, 3.0], size=(n_per_prim, 1))
+        targets.append(c + u * rad)
+    for i in range(v.ntriangles):
+        t = v.triangles[i]
+        A, B, Cc = (np.array([p.x, p.y, p.z]) for p in (t.u, t.v, t.w))
+        w = rng.uniform(-0.3, 1.3, size=(n_per_prim, 2))
+        w[: n_per_prim // 4] = rng.choice([0.0, 1.0, 0.5], size=(n_per_prim // 4, 2))   # vertices, edges
+        targets.append(A + w[:, :1] * (B - A) + w[:, 1:] * (Cc - A))
+    T = np.concatenate(targets) if targets else np.zeros((0, 3))
+    o = rng.uniform(-60, 60, size=T.shape)
+    o[::3] = T[::3] + rng.normal(size=T[::3].shape) * 0.5        # origins very close to the target
+    o[1::7] = [0.0, 0.0, 1.0]                                    # the bundled camera
+    d = T - o
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    d[::2] = -d[::2] if False else d[::2]
+    # half of the rays also point away (t < 0 side): the line still meets the primitive
+    d[5::11] = -d[5::11]
+    return o.astype(f32), d.astype(f32)
+
+
+SCENE_FILES = sorted(glob.glob(os.path.join(SCENES, "*.txt")))
+
+
+@pytest.mark.parametrize("path", SCENE_FILES, ids=[os.path.basename(p) for p in SCENE_FILES])
+def test_filter_never_rejects_an_accepted_pair(rt, oracle, path):
+    sc = rt.load_scene(path)
+    rec, guard = rt.filter_records(sc)
+    assert rec.shape == (sc.nprims, 4) and guard >= 16.0
+    rng = np.random.default_rng(7)
+    o, d = aimed_rays(sc, rng, 600)
+    acc = oracle.accept_matrix(sc, o, d).astype(bool)
+    P = filter_pass(rec, o, d)
+    assert acc.sum() > 1000, "test rays do not exercise the primitives"
+    viol = acc & ~P
+    assert not viol.any(), "filter rejected %d accepted pairs, primitives %s" % (viol.sum(), np.unique(np.argwhere(viol)[:, 1]))
+    # and it is a filter: far-away primitives are mostly rejected
+    finite = np.isfinite(rec[:, 3])
+    if finite.any():
+        assert P[:, finite].mean() < 0.9
+
+
+def test_filter_on_synthetic_c4(rt, oracle, tmp_path):
+    """The benchmark scene generator at reduced primitive count: 300 spheres (10 % affine) + 300 triangles."""
+    p = tmp_path / "c4s.txt"
+    rt.scenegen.write_c4(str(p), nspheres=300, ntriangles=300)
+    sc = rt.load_scene(str(p))
+    rec, guard = rt.filter_records(sc)
+    rng = np.random.default_rng(11)
+    o, d = aimed_rays(sc, rng, 24)
+    acc = oracle.accept_matrix(sc, o, d).astype(bool)
+    P = filter_pass(rec, o, d)
+    assert acc.sum() > 5000
+    assert not (acc & ~P).any()
+    # affine spheres of this generator have no translation row: they get a finite world-space bound
+    v = sc.view
+    xf = np.array([v.spheres[i].istransformed for i in range(v.nspheres)], dtype=bool)
+    assert xf.any() and np.isfinite(rec[: v.nspheres][xf, 3]).all()
+    # the filter's selectivity on this scene: a random pair passes rarely
+    assert P.mean() < 0.05
+
+
+def test_degenerate_primitives_always_pass(rt, tmp_path):
+    p = tmp_path / "deg.txt"
+    p.write_text("5\ncamera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0 0 0\n"
+                 "triangle 0 0 -5 0 0 -5 0 0 -5  1 1 1 1 1 1 1 1 1 0 0 1 1\n"         # a point
+                 "triangle 0 0 -5 1 0 -5 2 0 -5  1 1 1 1 1 1 1 1 1 0 0 1 1\n"         # collinear
+                 "sphere 0 0 -9 1  1 1 1 1 1 1 0 0 0 0 0 1 1 1  1 2 3 2 4 6 0 1 0 0 0 0\n"   # singular matrix
+                 "sphere 0 0 -9 1  1 1 1 1 1 1 0 0 0 0 0 1 1 1  1 0 0 0 1 0 0 0 1 .5 0 0\n"  # translation row
+                 "sphere 1 2 -9 2  1 1 1 1 1 1 0 0 0 0 0 1 0 1\n")
+    sc = rt.load_scene(str(p))
+    rec, _ = rt.filter_records(sc)
+    # order: spheres first (3), then triangles (2)
+    assert np.isneginf(rec[0, 3]) and np.isneginf(rec[1, 3]) and np.isfinite(rec[2, 3])
+    assert np.isneginf(rec[3, 3]) and np.isneginf(rec[4, 3])
+    assert rec[2, 3] <= -4.0 and rec[2, 3] > -4.01

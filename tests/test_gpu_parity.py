@@ -33,3 +33,40 @@ def test_scene_matches_oracle(rt, oracle, gpu, path, max_depth):
           f"({int((~same).sum())} px differ), rgb8 {r}")
     # float image: anything but the powf last-ulp cases must be bit-identical
     assert same.mean() >= 0.999, (os.path.basename(path), int((~same).sum()))
+
+
+@pytest.fixture(scope="module")
+def c4_scene(rt, tmp_path_factory):
+    """The benchmark's 10k-primitive scene (BASELINE.json configs[3]) with a 5 % refractive share,
+    so both kinds of secondary ray exist."""
+    p = tmp_path_factory.mktemp("c4") / "c4.txt"
+    rt.scenegen.write_c4(str(p), frac_refractive=0.05)
+    return rt.load_scene(str(p))
+
+
+def test_filter_is_exact_on_c4(rt, gpu, c4_scene):
+    """Size-independent property: the bounding-sphere filter may only skip work, never change a
+    result.  Filtered and exact-only renders of the 10k-primitive scene must agree bit for bit."""
+    W, H = 960, 540
+    a, sa = rt.render_f32(c4_scene, rt.Params.make(W, H, 4))
+    b, sb = rt.render_f32(c4_scene, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "filtered and exact-only float images differ on %d pixels" % int((~same).sum())
+    assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
+    ra, _ = rt.render_rgb8(c4_scene, rt.Params.make(W, H, 4))
+    rb, _ = rt.render_rgb8(c4_scene, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    assert np.array_equal(ra, rb)
+
+
+def test_c4_crop_matches_oracle(rt, oracle, gpu, c4_scene):
+    """The 10k-primitive scene at 4K geometry, rows 1000..1004 (5 x 3840 rays), against the oracle."""
+    W, H = 3840, 2160
+    row0, row1 = 1000, 1004
+    raw_cpu, cnt = oracle.render_f32(c4_scene, W, H, 4, row0, row1)
+    # one band that contains exactly those rows: band_rows = 4, rank owning band 250 of 540
+    p = rt.Params.make(W, H, 4, nranks=540, rank=250, band_rows=4)
+    raw_gpu, st = rt.render_f32(c4_scene, p)
+    assert raw_gpu.shape == raw_cpu.shape
+    same = raw_equal_mask(raw_gpu, raw_cpu)
+    print("c4 crop: %d of %d pixels bit-identical" % (int(same.sum()), same.size))
+    assert same.mean() >= 0.999
