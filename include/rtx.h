@@ -187,6 +187,10 @@ int  rtx_band_rows(int32_t height, int32_t nranks, int32_t rank, int32_t band_ro
  * a ray bypasses the filter.  out4 holds 4 * (nspheres + ntriangles) floats.  Lets the CPU test
  * suite prove the filter never rejects a pair the reference's test accepts. */
 int  rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out);
+/* The shadow-ray filter records of the affine spheres (16 floats each: rows a,b,c of the inverse's
+ * linear part, centre, -R^2, sphere index as int bits, 2 pad).  Returns the record count; out16
+ * may be NULL to query it. */
+int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t capacity);
 
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),

@@ -156,6 +156,58 @@ BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, doub
     return make(cw, (r * (1.0 + 1.0 / 16384.0) + slack) * nB);
 }
 
+// Shadow rays test an affine sphere with the ORIGIN left in world space and only the direction
+// mapped, td = normalize(ld*A + b) (raytracing.cpp:571-576).  The kernel's filter for that call
+// pattern recomputes q = ld*A with FMAs and tests the line (o, q) against the sphere (c, R):
+//     (1 + 2^-13) (q.X)^2 >= |q|^2 (|X|^2 - R^2)
+// Covered only when b == 0 and cond(A) <= 8, which bounds the angle between the binary32
+// direction the reference normalises and the filter's q by 2^-17; the 2^-13 factor and the
+// 2^-12 inflation of r^2 absorb that and the evaluation error.  Anything else always passes.
+AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im, int index)
+{
+    AffineShadowRec r = {im.a.x, im.a.y, im.a.z, im.b.x, im.b.y, im.b.z, im.c.x, im.c.y, im.c.z,
+                         s.center.x, s.center.y, s.center.z, -kInf, index, 0.0f, 0.0f};
+    if (im.d.x != 0 || im.d.y != 0 || im.d.z != 0) return r;
+    double A[3][3] = {{im.a.x, im.a.y, im.a.z}, {im.b.x, im.b.y, im.b.z}, {im.c.x, im.c.y, im.c.z}};
+    double n1 = 0, ninf = 0;
+    for (int i = 0; i < 3; i++) {
+        if (!std::isfinite(A[i][0]) || !std::isfinite(A[i][1]) || !std::isfinite(A[i][2])) return r;
+        ninf = std::max(ninf, std::fabs(A[i][0]) + std::fabs(A[i][1]) + std::fabs(A[i][2]));
+        n1 = std::max(n1, std::fabs(A[0][i]) + std::fabs(A[1][i]) + std::fabs(A[2][i]));
+    }
+    double nA = std::sqrt(n1 * ninf);
+    double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                 A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    if (!(std::fabs(det) > 1e-9 * nA * nA * nA) || nA == 0) return r;
+    // ||A^-1||_2 <= ||A||_F^2 / |det| for 3x3 (adjugate bound); use the cheap Frobenius form
+    double fro2 = 0;
+    for (auto& row : A)
+        for (double v : row) fro2 += v * v;
+    double nB = fro2 / std::fabs(det);  // >= ||adj(A)||_2 / |det| >= ||A^-1||_2
+    if (!(nA * nB <= 8.0)) {
+        // retry with the exact inverse norm bound before giving up
+        double B[3][3];
+        B[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; B[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+        B[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det; B[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+        B[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; B[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+        B[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det; B[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+        B[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+        double b1 = 0, binf = 0;
+        for (int i = 0; i < 3; i++) {
+            binf = std::max(binf, std::fabs(B[i][0]) + std::fabs(B[i][1]) + std::fabs(B[i][2]));
+            b1 = std::max(b1, std::fabs(B[0][i]) + std::fabs(B[1][i]) + std::fabs(B[2][i]));
+        }
+        nB = std::sqrt(b1 * binf);
+        if (!(nA * nB <= 8.0)) return r;
+    }
+    double rad = std::fabs((double)s.radius);
+    if (!std::isfinite(rad) || !finite3(d3(s.center))) return r;
+    double R2 = rad * rad * (1.0 + 1.0 / 4096.0) + 1e-30;
+    if (!(R2 < 1e37)) return r;
+    r.neg_r2 = -up(R2);
+    return r;
+}
+
 BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard)
 {
     D3 u = d3(t.u), v = d3(t.v), w = d3(t.w);

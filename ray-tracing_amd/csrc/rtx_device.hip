@@ -46,7 +46,6 @@ static thread_local std::string g_last_hip_error;
 constexpr int kBlock = 256;
 constexpr float kBias = 1e-4f;       // raytracing.cpp:447
 constexpr float kMaxT = 1e8f;        // raytracing.cpp:10 (float nearest = Max_t)
-constexpr int kRaysPerLane = 2;      // rays per lane in the filtered intersection kernels
 constexpr int kTFlag = 1 << 30;      // the reference's `transformed` flag, carried in the prim word
 
 // ------------------------------------------------------------------------------------------------
@@ -63,7 +62,9 @@ struct SceneDev {
     const rtx_light* lights;      // [nl]
     F3 ambient;
     const float4* bounds;         // [ns+nt] filter records { c, -R^2 } (rtx_bounds.cpp)
-    const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern
+    const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern (affine spheres never pass)
+    const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
+    int naff;
     float guard;                  // |origin component| beyond this: the ray bypasses the filter
 };
 
@@ -297,12 +298,8 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 }
 
 template <int R>
-__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
+__device__ __forceinline__ void closest_body(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
 {
-    __shared__ float4 tile[kTile];
-    const int n = *nrays;
-    const int base = blockIdx.x * (kBlock * R);
-    if (base >= n) return;  // block-uniform
     F3 o[R], d[R], nd[R], fo[R], fd[R];
     bool live[R], abn[R];
     HitAcc h[R];
@@ -364,6 +361,24 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
     }
 }
 
+// Few rays (deep, thin generations): one ray per lane so twice as many workgroups share the chip.
+constexpr int kSmallRays = 1 << 20;
+
+__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
+{
+    __shared__ float4 tile[kTile];
+    const int n = *nrays;
+    if (n > kSmallRays) {
+        const int base = blockIdx.x * (kBlock * 2);
+        if (base >= n) return;  // block-uniform
+        closest_body<2>(S, L, n, base, tile);
+    } else {
+        const int base = blockIdx.x * kBlock;
+        if (base >= n) return;
+        closest_body<1>(S, L, n, base, tile);
+    }
+}
+
 // exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
 __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld, F3 nld)
 {
@@ -380,12 +395,8 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
 }
 
 template <int R>
-__global__ __launch_bounds__(kBlock) void k_shadow_f(SceneDev S, LevelDev L, const int* nnodes)
+__device__ __forceinline__ void shadow_body(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
 {
-    __shared__ float4 tile[kTile];
-    const int n = *nnodes;
-    const int base = blockIdx.x * (kBlock * R);
-    if (base >= n) return;  // block-uniform
     const int li = blockIdx.y;
     const rtx_light& Lt = S.lights[li];
     F3 o[R], ld[R], nld[R], fo[R], fd[R];
@@ -451,11 +462,76 @@ __global__ __launch_bounds__(kBlock) void k_shadow_f(SceneDev S, LevelDev L, con
             }
         }
     }
+    // Affine spheres (any-hit is order independent, so they can come last): the reference maps only
+    // the DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against
+    // the sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
+    constexpr int kAffTile = kTile / 4;
+    for (int a0 = 0; a0 < S.naff; a0 += kAffTile) {
+        bool alldone = true;
+#pragma unroll
+        for (int r = 0; r < R; r++) alldone = alldone && done[r];
+        if (__syncthreads_and(alldone)) break;
+        int cnt = min(kAffTile, S.naff - a0);
+        for (int j = threadIdx.x; j < cnt * 4; j += kBlock) tile[j] = S.aff_shadow[(size_t)a0 * 4 + j];
+        __syncthreads();
+        if (__all(alldone)) continue;
+        for (int u = 0; u < cnt; u++) {
+            float4 m0 = tile[4 * u], m1 = tile[4 * u + 1], m2 = tile[4 * u + 2], m3 = tile[4 * u + 3];
+            // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
+            bool want = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                F3 l = ld[r];
+                float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
+                float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
+                float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
+                float X = o[r].x - m2.y, Y = o[r].y - m2.z, Z = o[r].z - m2.w;
+                float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
+                float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+                float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
+                float F = __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
+                want = want || (!done[r] && (abn[r] || !(F < 0.0f)));
+            }
+            if (want) {
+                int k = __float_as_int(m3.y);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    F3 l = ld[r];
+                    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
+                    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
+                    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
+                    float X = o[r].x - m2.y, Y = o[r].y - m2.z, Z = o[r].z - m2.w;
+                    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
+                    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+                    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
+                    float F = __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
+                    if (!done[r] && (abn[r] || !(F < 0.0f))) {
+                        if (exact_any(S, k, o[r], ld[r], nld[r])) done[r] = true;
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         int j = base + r * kBlock + threadIdx.x;
         // done && live  <=>  some primitive blocks the light
         if (live[r]) L.lit[(size_t)li * L.cap + j] = done[r] ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow_f(SceneDev S, LevelDev L, const int* nnodes)
+{
+    __shared__ float4 tile[kTile];
+    const int n = *nnodes;
+    if ((long long)n * S.nl > kSmallRays) {
+        const int base = blockIdx.x * (kBlock * 2);
+        if (base >= n) return;  // block-uniform
+        shadow_body<2>(S, L, n, base, tile);
+    } else {
+        const int base = blockIdx.x * kBlock;
+        if (base >= n) return;
+        shadow_body<1>(S, L, n, base, tile);
     }
 }
 
@@ -836,6 +912,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&bnds, P.bounds_shadow.size()))) return rc;
         if (!P.bounds_shadow.empty()) HIPCHK(hipMemcpy(bnds, P.bounds_shadow.data(), P.bounds_shadow.size() * sizeof(float4), hipMemcpyHostToDevice));
         c->S.bounds_shadow = bnds;
+        static_assert(sizeof(AffineShadowRec) == 4 * sizeof(float4), "affine shadow record is four float4");
+        float4* aff = nullptr;
+        if ((rc = c->dalloc(&aff, P.aff_shadow.size() * 4))) return rc;
+        if (!P.aff_shadow.empty()) HIPCHK(hipMemcpy(aff, P.aff_shadow.data(), P.aff_shadow.size() * sizeof(AffineShadowRec), hipMemcpyHostToDevice));
+        c->S.aff_shadow = aff;
+        c->S.naff = (int)P.aff_shadow.size();
         c->S.guard = P.guard;
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
@@ -933,7 +1015,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else hipLaunchKernelGGL(k_closest_f<kRaysPerLane>, dim3((g + kRaysPerLane - 1) / kRaysPerLane), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else hipLaunchKernelGGL(k_closest_f, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
@@ -941,7 +1023,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
                 if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
                 else if (exact_only) hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
-                else hipLaunchKernelGGL(k_shadow_f<kRaysPerLane>, dim3((g + kRaysPerLane - 1) / kRaysPerLane, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
+                else hipLaunchKernelGGL(k_shadow_f, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             }
             if (c->fanout >= 2) live_cap *= 2;

@@ -2,6 +2,7 @@
 #include "rtx_pack.h"
 
 #include <cmath>
+#include <cstring>
 #include <limits>
 
 namespace rtx {
@@ -119,7 +120,10 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
     for (size_t i = 0; i < P.tri.size(); i++) P.bounds.push_back(bound_sphere_triangle(P.tri[i], guard));
     P.bounds_shadow = P.bounds;
     for (size_t i = 0; i < P.sph.size(); i++)
-        if (P.sph[i].istransformed) P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+        if (P.sph[i].istransformed) {
+            P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};  // never passes the main loop
+            P.aff_shadow.push_back(affine_shadow_record(P.sph[i], P.sph_im[i], (int)i));
+        }
 
     // camera basis, raytracing.cpp:725-737
     P.camera = sc.camera;
@@ -161,4 +165,18 @@ extern "C" int rtx_filter_records(const rtx_scene* scene, float* out4, float* gu
     }
     if (guard_out) *guard_out = P.guard;
     return RTX_OK;
+}
+
+extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t capacity)
+{
+    if (!scene || (scene->nspheres && !scene->spheres)) return RTX_E_INVALID_ARG;
+    rtx::PackedScene P;
+    rtx::pack_scene(*scene, 1, 1, P);
+    int n = (int)P.aff_shadow.size();
+    if (out16) {
+        if (capacity < n) return RTX_E_INVALID_ARG;
+        static_assert(sizeof(rtx::AffineShadowRec) == 64, "16 floats");
+        if (n) std::memcpy(out16, P.aff_shadow.data(), (size_t)n * 64);
+    }
+    return n;
 }

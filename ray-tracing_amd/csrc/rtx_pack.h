@@ -36,10 +36,18 @@ BoundSphere bound_sphere_plain(const rtx_sphere& s);
 BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, double guard);
 BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard);
 
+// 64-byte filter record of one affine sphere for SHADOW rays (raytracing.cpp:571-576: the
+// direction is inverse-transformed, the origin is not): rows of the inverse's linear part, the
+// centre, -R^2 (inflated; -inf = always pass) and the sphere's index.
+struct AffineShadowRec { float ax, ay, az, bx, by, bz, cx, cy, cz, ox, oy, oz, neg_r2; int32_t index; float pad0, pad1; };
+AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im, int index);
+
 struct PackedScene {
+    std::vector<AffineShadowRec> aff_shadow;  // one per affine sphere, file order
     std::vector<BoundSphere> bounds;     // [nspheres + ntriangles], closest-hit call pattern
     std::vector<BoundSphere> bounds_shadow; // same for shadow rays: affine spheres always pass there, because
-                                         // the reference transforms only the direction, not the origin (:571-576)
+                                         // the reference transforms only the direction, not the origin (:571-576);
+                                         // here they NEVER pass, and are handled through aff_shadow instead
     float guard = 1.0f;                  // rays with an origin component beyond this bypass the filter
     std::vector<SphHot>      sph_hot;
     std::vector<int32_t>     sph_xf;     // istransformed (:34)

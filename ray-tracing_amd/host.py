@@ -106,6 +106,7 @@ SYMBOLS = {
     "rtx_context_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtx_band_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.POINTER(C.c_float)]),
+    "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
     "rtx_write_ppm": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -210,6 +211,15 @@ def filter_records(scene):
     g = C.c_float()
     _check(lib().rtx_filter_records(scene.ptr, out.ctypes.data, C.byref(g)), "rtx_filter_records")
     return out, g.value
+
+
+def affine_shadow_records(scene):
+    """records[naffine,16] float32 (index field viewed as int32 at column 13)."""
+    n = _check(lib().rtx_affine_shadow_records(scene.ptr, None, 0), "rtx_affine_shadow_records")
+    out = np.zeros((n, 16), dtype=np.float32)
+    if n:
+        _check(lib().rtx_affine_shadow_records(scene.ptr, out.ctypes.data, n), "rtx_affine_shadow_records")
+    return out
 
 
 def write_ppm(path, rgb):
