@@ -92,7 +92,7 @@ typedef struct rtx_params {
     int32_t  band_rows;    /* rows per band */
     int32_t  device;       /* HIP device ordinal; -1 = current device */
     uint32_t flags;        /* RTX_F_* */
-    uint64_t workspace_bytes; /* cap on per-context ray-queue memory; 0 = default (8 GiB) */
+    uint64_t workspace_bytes; /* cap on per-context ray-queue memory; 0 = default (32 GiB) */
 } rtx_params;
 
 #define RTX_F_NONE          0u
@@ -113,8 +113,11 @@ typedef struct rtx_stats {
     uint64_t rays_level[RTX_MAX_LEVELS]; /* rays per generation */
     uint64_t tests_closest;     /* ray x primitive tests executed by closest-hit (rays * nprims) */
     uint64_t tests_shadow_max;  /* upper bound for shadow rays (no early exit): rays * nprims */
-    /* RTX_F_COUNT_TESTS only: tests executed by kind {sphere, affine sphere, triangle full path,
-     * triangle leaving at vd == 0 or t < 0}; the shadow counts reflect the any-hit early exit */
+    /* Tests executed by kind {sphere, affine sphere, triangle full path, triangle leaving at vd == 0
+     * or t < 0}.  With RTX_F_COUNT_TESTS: counted by the exact kernels (shadow rays: per-ray early exit
+     * in file order).  Otherwise tests_shadow_kind reports what the chunked shadow passes evaluated
+     * (rays alive at the start of a pass x primitives of the pass; triangles all under [2]) and
+     * tests_closest_kind stays 0. */
     uint64_t tests_closest_kind[4];
     uint64_t tests_shadow_kind[4];
     uint64_t singular_matrices; /* transformed spheres whose matrix has det == 0 (:148) */

@@ -65,6 +65,9 @@ struct SceneDev {
     const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern (affine spheres never pass)
     const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
     int naff;
+    const float4* sbounds;        // [nsb] shadow-ordered filter records (no affine spheres), big occluders first
+    const int* sorder;            // [nsb] primitive index of each
+    int nsb;
     float guard;                  // |origin component| beyond this: the ray bypasses the filter
 };
 
@@ -270,7 +273,7 @@ __device__ __forceinline__ int stage_tile(float4* tile, const float4* bounds, in
     return cnt;
 }
 
-struct HitAcc { float nearest; int best; int tflag; };
+struct HitAcc { float nearest; int best; int tflag; float txf; };  // txf: t of the last affine-sphere record (thin mode)
 
 // exact closest-hit update for primitive k (wave-uniform), raytracing.cpp:385-403 / :407-418
 __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3 d, F3 nd, HitAcc& h)
@@ -286,7 +289,7 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
         }
         float t;
         if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
-            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) h.tflag = kTFlag; }
+            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) { h.tflag = kTFlag; h.txf = t; } }
         }
     } else {
         TriRec T = load_tri(S.tri_hot, k - S.ns);
@@ -319,7 +322,7 @@ __device__ __forceinline__ void closest_body(const SceneDev& S, const LevelDev& 
         fd[r] = use ? f3(nd[r].x * kDirScale, nd[r].y * kDirScale, nd[r].z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
         accinit[r] = (live[r] && abn[r]) ? 0u : 0xFFFFFFFFu;  // abnormal lanes always take the exact path
         asm volatile("" : "+v"(accinit[r]));                  // keep it a plain v_and operand (no v_cndmask)
-        h[r].nearest = kMaxT; h[r].best = -1; h[r].tflag = 0;
+        h[r].nearest = kMaxT; h[r].best = -1; h[r].tflag = 0; h[r].txf = kMaxT;
     }
     const int nprim = S.ns + S.nt;
     for (int t0 = 0; t0 < nprim; t0 += kTile) {
@@ -361,8 +364,85 @@ __device__ __forceinline__ void closest_body(const SceneDev& S, const LevelDev& 
     }
 }
 
-// Few rays (deep, thin generations): one ray per lane so twice as many workgroups share the chip.
+// Fewer rays: one ray per lane so twice as many workgroups share the chip.
 constexpr int kSmallRays = 1 << 20;
+
+// Thin generations (deep bounces: few, incoherent rays).  A workgroup takes only 64 rays and its
+// four waves split the primitive list into four contiguous slices, so a generation of a few
+// thousand rays still puts a wave on every SIMD and the serial walk per wave is 4x shorter.
+// The slices are merged in index order, which reproduces the sequential scan exactly: slice p's
+// nearest hit wins iff it is strictly nearer than everything before it, and the reference's sticky
+// `transformed` flag (:396-399) is set iff some slice's last affine-sphere record beats the minimum
+// of the slices before it.
+constexpr int kThinRays = 1 << 18;
+constexpr int kThinTile = kTile / 4;
+
+__device__ __forceinline__ int stage_thin(float4* mt, const float4* bounds, int t0, int end, int lane)
+{
+    int cnt = max(0, min(kThinTile, end - t0));
+    for (int j = lane; j < cnt; j += 64) mt[j] = bounds[t0 + j];
+    int padded = (cnt + kGroup - 1) / kGroup * kGroup;
+    for (int j = cnt + lane; j < padded; j += 64) mt[j] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+    return cnt;
+}
+
+__device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& L, const int n, float4* tile)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;  // the four waves hold the same 64 rays
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
+    F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
+    F3 nd = normalized(d);
+    const bool abn = ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(accinit));
+    HitAcc h;
+    h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
+    const int nprim = S.ns + S.nt;
+    const int SL = ((nprim + kGroup - 1) / kGroup + 3) / 4 * kGroup;  // primitives per slice, whole groups
+    const int p0 = min(w * SL, nprim), p1 = min(p0 + SL, nprim);
+    const int T = (SL + kThinTile - 1) / kThinTile;
+    float4* mt = tile + w * kThinTile;
+    for (int tt = 0; tt < T; tt++) {
+        __syncthreads();
+        const int t0 = p0 + tt * kThinTile;
+        const int cnt = stage_thin(mt, S.bounds, t0, p1, lane);
+        __syncthreads();
+        for (int g = 0; g < cnt; g += kGroup) {
+            unsigned acc = accinit;
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, mt[g + u]));
+            if ((int)acc >= 0) {
+                int gend = min(kGroup, cnt - g);
+                for (int u = 0; u < gend; u++)
+                    if (live && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h);
+            }
+        }
+    }
+    __syncthreads();
+    float* rt = reinterpret_cast<float*>(tile);
+    int* rb = reinterpret_cast<int*>(tile) + 256;
+    float* rx = reinterpret_cast<float*>(tile) + 512;
+    rt[threadIdx.x] = h.nearest; rb[threadIdx.x] = h.best; rx[threadIdx.x] = h.txf;
+    __syncthreads();
+    if (w == 0 && live) {
+        float m = kMaxT;
+        int best = -1, flag = 0;
+        for (int p = 0; p < 4; p++) {
+            if (rx[p * 64 + lane] < m) flag = kTFlag;
+            float tp = rt[p * 64 + lane];
+            if (tp < m) { m = tp; best = rb[p * 64 + lane]; }
+        }
+        if (best >= S.ns) flag = 0;  // a triangle won: :416
+        L.t[i] = m;
+        L.prim[i] = (best < 0) ? -1 : (best | flag);
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
 {
@@ -372,10 +452,13 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
         const int base = blockIdx.x * (kBlock * 2);
         if (base >= n) return;  // block-uniform
         closest_body<2>(S, L, n, base, tile);
-    } else {
+    } else if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;
         closest_body<1>(S, L, n, base, tile);
+    } else {
+        if (blockIdx.x * 64 >= n) return;
+        closest_thin(S, L, n, tile);
     }
 }
 
@@ -394,24 +477,51 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
     return triangle_test(o, ld, T, t, vd);
 }
 
-template <int R>
-__device__ __forceinline__ void shadow_body(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
+// Shadow rays (raytracing.cpp:560-589) are any-hit: which primitive blocks the light first does not
+// matter, only whether one does.  So they are not traced in file order in one long loop.  They are
+// materialised once per generation (k_shadow_gen), then pushed through the primitive list in CHUNKS,
+// largest expected occluders first (SceneDev::sbounds); after every chunk the rays still unblocked
+// are compacted into the next queue with a wave64 ballot (k_shadow_pass), so waves stay full while
+// the ray population collapses (96 % of the benchmark scene's shadow rays are blocked).  Affine
+// spheres come last, through their own filter (k_shadow_aff).
+struct ShadowQ { float *ox, *oy, *oz, *dx, *dy, *dz; int* id; };
+
+__global__ __launch_bounds__(kBlock) void k_shadow_gen(SceneDev S, LevelDev L, const int* nnodes, ShadowQ Q, int* qcount)
 {
+    const int n = *nnodes;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
     const int li = blockIdx.y;
+    if (j == 0 && li == 0) *qcount = n * S.nl;
+    if (j >= n) return;
     const rtx_light& Lt = S.lights[li];
+    F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
+    F3 nn = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
+    F3 ld = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));  // :561-562
+    const int q = li * n + j;  // rays towards one light stay together: coherent waves
+    Q.ox[q] = ip.x + nn.x * kBias; Q.oy[q] = ip.y + nn.y * kBias; Q.oz[q] = ip.z + nn.z * kBias;  // :568
+    Q.dx[q] = ld.x; Q.dy[q] = ld.y; Q.dz[q] = ld.z;
+    const int id = li * L.cap + j;
+    Q.id[q] = id;
+    L.lit[id] = 1;  // until some primitive blocks it
+}
+
+template <int R>
+__device__ __forceinline__ void shadow_pass_body(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n, const int base,
+                                                 const int c0, const int c1, int* cnt_out, unsigned char* lit, float4* tile)
+{
     F3 o[R], ld[R], nld[R], fo[R], fd[R];
     bool live[R], abn[R], done[R];
+    int id[R];
     unsigned accinit[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int j = base + r * kBlock + threadIdx.x;
-        live[r] = j < n;
-        int jj = live[r] ? j : 0;
-        F3 ip = f3(L.n_px[jj], L.n_py[jj], L.n_pz[jj]);
-        F3 nn = f3(L.n_nx[jj], L.n_ny[jj], L.n_nz[jj]);
-        ld[r] = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));
-        o[r] = f3(ip.x + nn.x * kBias, ip.y + nn.y * kBias, ip.z + nn.z * kBias);
-        nld[r] = normalized(ld[r]);
+        int i = base + r * kBlock + threadIdx.x;
+        live[r] = i < n;
+        int ii = live[r] ? i : 0;
+        o[r] = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
+        ld[r] = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+        id[r] = Qi.id[ii];
+        nld[r] = normalized(ld[r]);  // :575 for untransformed spheres
         abn[r] = ray_abnormal(o[r], ld[r], nld[r], S.guard);
         bool use = live[r] && !abn[r];
         fo[r] = use ? o[r] : f3(1e18f, 0.0f, 0.0f);
@@ -420,13 +530,12 @@ __device__ __forceinline__ void shadow_body(const SceneDev& S, const LevelDev& L
         asm volatile("" : "+v"(accinit[r]));
         done[r] = !live[r];
     }
-    const int nprim = S.ns + S.nt;
-    for (int t0 = 0; t0 < nprim; t0 += kTile) {
+    for (int t0 = c0; t0 < c1; t0 += kTile) {
         bool alldone = true;
 #pragma unroll
         for (int r = 0; r < R; r++) alldone = alldone && done[r];
-        if (__syncthreads_and(alldone)) break;  // every ray of the block is in shadow
-        int cnt = stage_tile(tile, S.bounds_shadow, t0, nprim);
+        if (__syncthreads_and(alldone)) break;  // every ray of the workgroup is blocked
+        int cnt = stage_tile(tile, S.sbounds, t0, c1);
         __syncthreads();
         if (__all(alldone)) continue;  // this wave is finished; it only keeps the barriers company
         for (int g = 0; g < cnt; g += kGroup) {
@@ -446,12 +555,12 @@ __device__ __forceinline__ void shadow_body(const SceneDev& S, const LevelDev& L
                 int gend = min(kGroup, cnt - g);
                 for (int u = 0; u < gend; u++) {
                     float4 b = tile[g + u];
-                    int k = t0 + g + u;
+                    int k = S.sorder[t0 + g + u];
 #pragma unroll
                     for (int r = 0; r < R; r++)
                         if (!done[r] && (abn[r] || !(filt(fo[r], fd[r], b) < 0.0f))) {
                             if (exact_any(S, k, o[r], ld[r], nld[r])) {
-                                done[r] = true;  // in shadow: stop passing the filter from here on
+                                done[r] = true;  // blocked: stop passing the filter from here on
                                 fo[r] = f3(1e18f, 0.0f, 0.0f);
                                 fd[r] = f3(0.0f, 0.0f, 0.0f);
                                 accinit[r] = 0xFFFFFFFFu;
@@ -462,77 +571,153 @@ __device__ __forceinline__ void shadow_body(const SceneDev& S, const LevelDev& L
             }
         }
     }
-    // Affine spheres (any-hit is order independent, so they can come last): the reference maps only
-    // the DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against
-    // the sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
-    constexpr int kAffTile = kTile / 4;
-    for (int a0 = 0; a0 < S.naff; a0 += kAffTile) {
-        bool alldone = true;
-#pragma unroll
-        for (int r = 0; r < R; r++) alldone = alldone && done[r];
-        if (__syncthreads_and(alldone)) break;
-        int cnt = min(kAffTile, S.naff - a0);
-        for (int j = threadIdx.x; j < cnt * 4; j += kBlock) tile[j] = S.aff_shadow[(size_t)a0 * 4 + j];
-        __syncthreads();
-        if (__all(alldone)) continue;
-        for (int u = 0; u < cnt; u++) {
-            float4 m0 = tile[4 * u], m1 = tile[4 * u + 1], m2 = tile[4 * u + 2], m3 = tile[4 * u + 3];
-            // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
-            bool want = false;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                F3 l = ld[r];
-                float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
-                float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
-                float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
-                float X = o[r].x - m2.y, Y = o[r].y - m2.z, Z = o[r].z - m2.w;
-                float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
-                float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
-                float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
-                float F = __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
-                want = want || (!done[r] && (abn[r] || !(F < 0.0f)));
-            }
-            if (want) {
-                int k = __float_as_int(m3.y);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    F3 l = ld[r];
-                    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
-                    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
-                    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
-                    float X = o[r].x - m2.y, Y = o[r].y - m2.z, Z = o[r].z - m2.w;
-                    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
-                    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
-                    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
-                    float F = __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
-                    if (!done[r] && (abn[r] || !(F < 0.0f))) {
-                        if (exact_any(S, k, o[r], ld[r], nld[r])) done[r] = true;
-                    }
-                }
-            }
-        }
-    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int j = base + r * kBlock + threadIdx.x;
-        // done && live  <=>  some primitive blocks the light
-        if (live[r]) L.lit[(size_t)li * L.cap + j] = done[r] ? 0 : 1;
+        bool survive = live[r] && !done[r];
+        int slot = wave_alloc(survive, cnt_out);  // ballot-compacted queue of the rays still unblocked
+        if (survive) {
+            Qo.ox[slot] = o[r].x; Qo.oy[slot] = o[r].y; Qo.oz[slot] = o[r].z;
+            Qo.dx[slot] = ld[r].x; Qo.dy[slot] = ld[r].y; Qo.dz[slot] = ld[r].z;
+            Qo.id[slot] = id[r];
+        } else if (live[r]) {
+            lit[id[r]] = 0;
+        }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_shadow_f(SceneDev S, LevelDev L, const int* nnodes)
+// Thin-generation form of a shadow pass: 64 rays per workgroup, the pass's chunk split over the
+// four waves; a ray is blocked if any wave found a blocker (any-hit: plain OR).
+__device__ __forceinline__ void shadow_pass_thin(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n,
+                                                 const int c0, const int c1, int* cnt_out, unsigned char* lit, float4* tile)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
+    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+    const int id = Qi.id[ii];
+    F3 nld = normalized(ld);
+    const bool abn = ray_abnormal(o, ld, nld, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(accinit));
+    bool done = !live;
+    const int SL = (((c1 - c0) + kGroup - 1) / kGroup + 3) / 4 * kGroup;
+    const int p0 = min(c0 + w * SL, c1), p1 = min(p0 + SL, c1);
+    const int T = (SL + kThinTile - 1) / kThinTile;
+    float4* mt = tile + w * kThinTile;
+    for (int tt = 0; tt < T; tt++) {
+        __syncthreads();
+        const int t0 = p0 + tt * kThinTile;
+        const int cnt = stage_thin(mt, S.sbounds, t0, p1, lane);
+        __syncthreads();
+        if (__all(done)) continue;
+        for (int g = 0; g < cnt; g += kGroup) {
+            unsigned acc = accinit;
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, mt[g + u]));
+            if ((int)acc >= 0) {
+                int gend = min(kGroup, cnt - g);
+                for (int u = 0; u < gend; u++)
+                    if (!done && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) {
+                        if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
+                            done = true;
+                            fo = f3(1e18f, 0.0f, 0.0f);
+                            fd = f3(0.0f, 0.0f, 0.0f);
+                            accinit = 0xFFFFFFFFu;
+                            asm volatile("" : "+v"(accinit));
+                        }
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    int* blocked = reinterpret_cast<int*>(tile);
+    blocked[threadIdx.x] = (live && done) ? 1 : 0;
+    __syncthreads();
+    if (w == 0) {
+        bool b = (blocked[lane] | blocked[64 + lane] | blocked[128 + lane] | blocked[192 + lane]) != 0;
+        bool survive = live && !b;
+        int slot = wave_alloc(survive, cnt_out);
+        if (survive) {
+            Qo.ox[slot] = o.x; Qo.oy[slot] = o.y; Qo.oz[slot] = o.z;
+            Qo.dx[slot] = ld.x; Qo.dy[slot] = ld.y; Qo.dz[slot] = ld.z;
+            Qo.id[slot] = id;
+        } else if (live) {
+            lit[id] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, ShadowQ Qo, const int* cnt_in, int* cnt_out,
+                                                        int c0, int c1, unsigned char* lit)
 {
     __shared__ float4 tile[kTile];
-    const int n = *nnodes;
-    if ((long long)n * S.nl > kSmallRays) {
+    const int n = *cnt_in;
+    if (n > kSmallRays) {
         const int base = blockIdx.x * (kBlock * 2);
         if (base >= n) return;  // block-uniform
-        shadow_body<2>(S, L, n, base, tile);
-    } else {
+        shadow_pass_body<2>(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, tile);
+    } else if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;
-        shadow_body<1>(S, L, n, base, tile);
+        shadow_pass_body<1>(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, tile);
+    } else {
+        if (blockIdx.x * 64 >= n) return;
+        shadow_pass_thin(S, Qi, Qo, n, c0, c1, cnt_out, lit, tile);
     }
+}
+
+// Affine spheres against the rays that survived every other primitive.  The reference maps only the
+// DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against the
+// sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
+__device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, float4 m2, float4 m3)
+{
+    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
+    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
+    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
+    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
+    float X = o.x - m2.y, Y = o.y - m2.z, Z = o.z - m2.w;
+    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
+    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
+    return __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow_aff(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit)
+{
+    __shared__ float4 tile[kTile];
+    const int n = *cnt_in;
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    const int i = base + threadIdx.x;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
+    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+    const int id = Qi.id[ii];
+    F3 nld = normalized(ld);
+    const bool abn = ray_abnormal(o, ld, nld, S.guard);
+    bool done = !live;
+    constexpr int kAffTile = kTile / 4;
+    for (int a0 = 0; a0 < S.naff; a0 += kAffTile) {
+        if (__syncthreads_and(done)) break;
+        int cnt = min(kAffTile, S.naff - a0);
+        for (int j = threadIdx.x; j < cnt * 4; j += kBlock) tile[j] = S.aff_shadow[(size_t)a0 * 4 + j];
+        __syncthreads();
+        if (__all(done)) continue;
+        for (int u = 0; u < cnt; u++) {
+            float4 m0 = tile[4 * u], m1 = tile[4 * u + 1], m2 = tile[4 * u + 2], m3 = tile[4 * u + 3];
+            float F = filt_affine(o, ld, m0, m1, m2, m3);
+            if (!done && (abn || !(F < 0.0f))) {
+                if (exact_any(S, __float_as_int(m3.y), o, ld, nld)) done = true;
+            }
+        }
+    }
+    if (live && done) lit[id] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,6 +989,11 @@ struct rtx_context {
     int* d_cnt = nullptr;                   // [2*levels]: rays per level, then nodes per level
     unsigned long long* d_totals = nullptr; // [2*levels]
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
+    ShadowQ sq[2] = {};                     // ping-pong shadow-ray queues
+    std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
+    int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
+    int scnt_stride = 0, nframe_chunks = 0;
+    std::vector<int> sb_kind;               // kind (0 sphere, 2 triangle) of each shadow-ordered primitive
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest, 1 shadow, per pair used by the last render
@@ -918,6 +1108,19 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (!P.aff_shadow.empty()) HIPCHK(hipMemcpy(aff, P.aff_shadow.data(), P.aff_shadow.size() * sizeof(AffineShadowRec), hipMemcpyHostToDevice));
         c->S.aff_shadow = aff;
         c->S.naff = (int)P.aff_shadow.size();
+        float4* sb = nullptr; int* so = nullptr;
+        if ((rc = c->dalloc(&sb, P.sbounds.size()))) return rc;
+        if (!P.sbounds.empty()) HIPCHK(hipMemcpy(sb, P.sbounds.data(), P.sbounds.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if ((rc = c->upload(&so, P.sorder))) return rc;
+        c->S.sbounds = sb; c->S.sorder = so; c->S.nsb = (int)P.sbounds.size();
+        for (int32_t k : P.sorder) c->sb_kind.push_back(k < (int)P.sph.size() ? 0 : 2);
+        // shadow pass schedule: a pass costs about as much as ~300 primitives per ray, so chunks of 1-2 k
+        c->sched.push_back(0);
+        for (int pos = 0, step = 1024, i = 0; pos < c->S.nsb; i++) {
+            pos = std::min(c->S.nsb, pos + step);
+            c->sched.push_back(pos);
+            if (i >= 3) step = 2048;
+        }
         c->S.guard = P.guard;
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
@@ -942,13 +1145,14 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
     double mult = 0, m = 1;
     for (int k = 0; k < levels; k++) { mult += m; m *= (c->fanout >= 2 ? 2.0 : 1.0); }
-    uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)8 << 30);
-    double per_row = (double)W * mult * (double)slot_bytes;
+    uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
+    // per level-0 ray: every level's slots, plus the two shadow-ray queues sized for the largest level
+    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * 2.0 * 28.0 * (double)c->S.nl);
     int64_t rows = (int64_t)((double)budget / per_row);
     if (rows < 1) rows = 1;
     if (rows > ntrace) rows = ntrace;
     // the deepest level's capacity must stay indexable by int
-    while (rows > 1 && (double)rows * W * (m / (c->fanout >= 2 ? 2.0 : 1.0)) > (double)((int64_t)1 << 30)) rows /= 2;
+    while (rows > 1 && (double)rows * W * (m / (c->fanout >= 2 ? 2.0 : 1.0)) * std::max(c->S.nl, 1) > (double)((int64_t)1 << 30)) rows /= 2;
     c->chunk_rows = (int)std::max<int64_t>(rows, 1);
     if (ntrace == 0) c->chunk_rows = 1;
 
@@ -969,17 +1173,32 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&L.lit, cap * (size_t)std::max(c->S.nl, 1)))) return rc;
         if (c->fanout >= 2) cap *= 2;
     }
+    {   // shadow-ray queues: the largest generation's hits x lights
+        size_t qcap = (size_t)c->L[levels - 1].cap * (size_t)std::max(c->S.nl, 1);
+        if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
+        for (ShadowQ& q : c->sq) {
+            float** fl[] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz};
+            for (float** f : fl)
+                if ((rc = c->dalloc(f, qcap))) return rc;
+            if ((rc = c->dalloc(&q.id, qcap))) return rc;
+        }
+        c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
+        c->scnt_stride = (int)c->sched.size() + 1;
+        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride))) return rc;
+    }
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     if (params->flags & RTX_F_TIME_KERNELS) {
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
-        c->kev.resize((size_t)nchunks * levels * 2 * 2);
+        c->kev.resize((size_t)nchunks * levels * 2 * (1 + c->sched.size()));
         for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
     }
     return RTX_OK;
 }
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// intersection kernels: thin generations (<= kThinRays live rays) use 64 rays per workgroup
+static inline unsigned grid_for_isect(size_t cap) { return std::max(grid_for(cap), (unsigned)((std::min<size_t>(cap, kThinRays) + 63) / 64)); }
 
 static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
 {
@@ -989,6 +1208,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     HIPCHK(hipEventRecord(c->ev0, st));
     HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
     HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 8, st));
+    HIPCHK(hipMemsetAsync(c->d_scnt, 0, sizeof(int) * (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride, st));
     const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
     const bool exact_only = (c->params.flags & RTX_F_EXACT_ONLY) != 0;
     const bool timek = !c->kev.empty();
@@ -1015,16 +1235,29 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else hipLaunchKernelGGL(k_closest_f, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
-            if (c->S.nl > 0) {
+            if (c->S.nl > 0 && (count || exact_only)) {
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
                 if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
-                else if (exact_only) hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
-                else hipLaunchKernelGGL(k_shadow_f, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
+            } else if (c->S.nl > 0) {
+                // materialise the shadow rays, then chunked any-hit passes with compaction in between
+                int* sc = c->d_scnt + ((size_t)nchunks * levels + k) * c->scnt_stride;
+                hipLaunchKernelGGL(k_shadow_gen, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->sq[0], sc + 0);
+                unsigned gq = grid_for_isect(live_cap * (size_t)c->S.nl);
+                const int npass = (int)c->sched.size() - 1;
+                for (int p = 0; p < npass; p++) {
+                    if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
+                    hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, st, c->S, c->sq[p & 1], c->sq[(p + 1) & 1], sc + p, sc + p + 1,
+                                       c->sched[p], c->sched[p + 1], Lk.lit);
+                    if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
+                }
+                if (c->S.naff > 0)
+                    hipLaunchKernelGGL(k_shadow_aff, dim3(gq), dim3(kBlock), 0, st, c->S, c->sq[npass & 1], sc + npass, Lk.lit);
             }
             if (c->fanout >= 2) live_cap *= 2;
         }
@@ -1151,6 +1384,25 @@ int rtx_context_stats(rtx_context* c, rtx_stats* s)
     unsigned long long tk[8];
     HIPCHK(hipMemcpy(tk, c->d_tests, sizeof tk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = tk[k]; s->tests_shadow_kind[k] = tk[4 + k]; }
+    if (!(c->params.flags & (RTX_F_COUNT_TESTS | RTX_F_EXACT_ONLY)) && c->S.nl > 0) {
+        // chunked shadow passes: every ray alive at the start of a pass is tested against the whole chunk
+        std::vector<int> sc((size_t)std::max(c->nframe_chunks, 1) * c->levels * c->scnt_stride);
+        HIPCHK(hipMemcpy(sc.data(), c->d_scnt, sc.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const int npass = (int)c->sched.size() - 1;
+        std::vector<uint64_t> nsph(npass, 0), ntri(npass, 0);
+        for (int p = 0; p < npass; p++)
+            for (int i = c->sched[p]; i < c->sched[p + 1]; i++) (c->sb_kind[i] == 0 ? nsph[p] : ntri[p])++;
+        for (int k = 0; k < 4; k++) s->tests_shadow_kind[k] = 0;
+        for (int ch = 0; ch < c->nframe_chunks; ch++)
+            for (int k = 0; k < c->levels; k++) {
+                const int* q = sc.data() + ((size_t)ch * c->levels + k) * c->scnt_stride;
+                for (int p = 0; p < npass; p++) {
+                    s->tests_shadow_kind[0] += (uint64_t)q[p] * nsph[p];
+                    s->tests_shadow_kind[2] += (uint64_t)q[p] * ntri[p];
+                }
+                s->tests_shadow_kind[1] += (uint64_t)q[npass] * (uint64_t)c->S.naff;
+            }
+    }
     for (size_t e = 0; e < c->kev_kind.size(); e++) {
         float m = 0;
         HIPCHK(hipEventElapsedTime(&m, c->kev[2 * e], c->kev[2 * e + 1]));

@@ -1,7 +1,9 @@
 // rtx_pack.cpp -- see rtx_pack.h.  Build with -ffp-contract=off (no FMA on the host either).
 #include "rtx_pack.h"
 
+#include <algorithm>
 #include <cmath>
+#include <utility>
 #include <cstring>
 #include <limits>
 
@@ -124,6 +126,24 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
             P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};  // never passes the main loop
             P.aff_shadow.push_back(affine_shadow_record(P.sph[i], P.sph_im[i], (int)i));
         }
+
+    {   // shadow order: mean projected area, descending (sphere pi r^2, triangle area / 2); primitives the
+        // filter cannot bound (always pass: an exact test every time) go last
+        std::vector<std::pair<double, int32_t>> w;
+        const int ns = (int)P.sph.size();
+        for (int i = 0; i < ns; i++) {
+            if (P.sph[i].istransformed) continue;
+            double r = std::fabs((double)P.sph[i].radius);
+            bool bounded = std::isfinite(P.bounds[i].neg_r2);
+            w.push_back({bounded ? 3.141592653589793 * r * r : -1.0, i});
+        }
+        for (int i = 0; i < (int)P.tri.size(); i++) {
+            bool bounded = std::isfinite(P.bounds[ns + i].neg_r2);
+            w.push_back({bounded ? 0.5 * (double)P.tri_hot[i].q[7] : -1.0, ns + i});
+        }
+        std::stable_sort(w.begin(), w.end(), [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first > b.first; });
+        for (auto& e : w) { P.sorder.push_back(e.second); P.sbounds.push_back(P.bounds[e.second]); }
+    }
 
     // camera basis, raytracing.cpp:725-737
     P.camera = sc.camera;

@@ -44,6 +44,11 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
 
 struct PackedScene {
     std::vector<AffineShadowRec> aff_shadow;  // one per affine sphere, file order
+    // Shadow rays are any-hit: the order primitives are tried in cannot change the result, only how
+    // soon a blocked ray stops.  sbounds = filter records of every primitive except affine spheres,
+    // largest expected occluder first; sorder[i] = primitive index (sphere i | ns + triangle i).
+    std::vector<BoundSphere> sbounds;
+    std::vector<int32_t>     sorder;
     std::vector<BoundSphere> bounds;     // [nspheres + ntriangles], closest-hit call pattern
     std::vector<BoundSphere> bounds_shadow; // same for shadow rays: affine spheres always pass there, because
                                          // the reference transforms only the direction, not the origin (:571-576);
