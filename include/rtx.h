@@ -99,6 +99,8 @@ typedef struct rtx_params {
 #define RTX_F_TIME_KERNELS  1u  /* HIP events around every closest-hit and shadow launch -> rtx_stats.ms_closest/ms_shadow */
 #define RTX_F_EXACT_ONLY    4u  /* skip the bounding-sphere filter: run the reference's exact test on every
                                    (ray, primitive) pair.  Must give the identical image; used to check that. */
+#define RTX_F_NO_HALO       8u  /* accounting only: trace the owned rows without the one-row halo and skip the
+                                   antialias step (framebuffer undefined).  Gives a rank's UNIQUE ray counts. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
                                    exact ray x primitive tests executed, by kind -> rtx_stats.tests_*_kind */
 

@@ -1057,8 +1057,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if (nown) rtx_band_rows(H, params->nranks, params->rank, params->band_rows, c->own_rows.data(), nown);
     c->row2ti.assign(H, -1);
     std::vector<char> need(H, 0);
+    const int halo = (params->flags & RTX_F_NO_HALO) ? 0 : 1;
     for (int y : c->own_rows)
-        for (int yy = y - 1; yy <= y + 1; yy++)
+        for (int yy = y - halo; yy <= y + halo; yy++)
             if (yy >= 0 && yy < H) need[yy] = 1;
     for (int y = 0; y < H; y++)
         if (need[y]) { c->row2ti[y] = (int)c->trace_rows.size(); c->trace_rows.push_back(y); }
@@ -1268,7 +1269,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
         }
         hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
     }
-    if (nown > 0)
+    if (nown > 0 && !(c->params.flags & RTX_F_NO_HALO))
         hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
                            c->d_own_rows, nown, W, c->height, d_out ? d_out : c->d_rgb8);
     HIPCHK(hipGetLastError());

@@ -11,6 +11,7 @@ RTX_MAX_LEVELS = 32
 F_TIME_KERNELS = 1
 F_COUNT_TESTS = 2
 F_EXACT_ONLY = 4
+F_NO_HALO = 8
 
 
 class RtxError(RuntimeError):

@@ -113,3 +113,19 @@ def test_c5_like_triangles_only(rt, oracle, gpu, tmp_path):
     rg, _ = rt.render_rgb8(sc, rt.Params.make(W, H, D))
     rc, _ = oracle.render_rgb8(sc, W, H, D)
     assert_rgb8_parity(rg, rc, "c5-like")
+
+
+def test_no_halo_counts_sum_to_the_frame(rt, gpu):
+    """RTX_F_NO_HALO (accounting flag used by bench.py at N > 1): the ranks' unique ray counts add
+    up to exactly the single-GPU frame's."""
+    W, H, N, B = 200, 150, 4, 9
+    sc = rt.load_scene(os.path.join(SCENES, "room.txt"))
+    _, full = rt.render_f32(sc, rt.Params.make(W, H, 4))
+    tot = [0, 0, 0]
+    for r in range(N):
+        ctx = rt.Context(sc, rt.Params.make(W, H, 4, nranks=N, rank=r, band_rows=B, flags=rt.host.F_NO_HALO))
+        ctx.render()
+        st = ctx.stats()
+        tot = [tot[0] + st.rays_primary, tot[1] + st.rays_secondary, tot[2] + st.rays_shadow]
+        ctx.close()
+    assert tot == [full.rays_primary, full.rays_secondary, full.rays_shadow]
