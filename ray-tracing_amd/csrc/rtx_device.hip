@@ -364,8 +364,142 @@ __device__ __forceinline__ void closest_body(const SceneDev& S, const LevelDev& 
     }
 }
 
-// Fewer rays: one ray per lane so twice as many workgroups share the chip.
-constexpr int kSmallRays = 1 << 20;
+
+// ------------------------------------------------------------------------------------------------
+// Packet test.  A wave's 64 rays are bounded by a sphere around their origins (co, rho) and a cone
+// around their directions (axis w, half-angle theta).  Each LANE then tests a DIFFERENT primitive's
+// bounding sphere against that packet (64 primitives per instruction instead of one), a ballot turns
+// the answers into a mask, and only primitives in the mask go through the per-ray filter (and, if
+// that passes, the exact test), in index order.  Coherent waves -- primary rays, shadow rays of
+// neighbouring pixels towards one light -- keep a handful of the 10,000 primitives.
+//
+// Conservative by construction: the per-ray filter passes only if the primitive's centre lies within
+// R of the double cone (apex o_i, axis d_i, half-angle atan sqrt(eps/(1-eps))), eps = 1.2e-5 bounding
+// the filter's 2^-18 direction scale and binary32 evaluation error relative to |X|^2; that cone is
+// inside the packet's cone widened by the same angle and thickened by rho.  The test below is
+//      dist(c - co, cone(w, theta')) <= R + rho     i.e.     h cos(theta') <= R + rho + a sin(theta')
+// with a = |w.C|, h^2 = |C|^2 - a^2, squared, every rounding pushed to the passing side.  Waves with an
+// abnormal lane, or a cone wider than ~70 degrees, do not use it (they take the grouped loop).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPacketDense = 20;  // more survivors than this in a batch of 64: use the grouped loop for the batch
+struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; bool ok; };
+
+__device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int m = 32; m; m >>= 1) v = fmaxf(v, __shfl_xor(v, m)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m); return v; }
+
+__device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn)
+{
+    Packet P;
+    unsigned long long lm = __ballot(live);
+    bool bad = __any(live && abn) || lm == 0;
+    int src = lm ? (__ffsll((long long)lm) - 1) : 0;
+    // dead lanes borrow a live lane's ray so they do not widen the bounds
+    F3 oo = f3(live ? o.x : __shfl(o.x, src), live ? o.y : __shfl(o.y, src), live ? o.z : __shfl(o.z, src));
+    F3 dd = f3(live ? nd.x : __shfl(nd.x, src), live ? nd.y : __shfl(nd.y, src), live ? nd.z : __shfl(nd.z, src));
+    float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
+    P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+    float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
+    P.rho = wave_max(sqrtf(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
+    F3 sw = f3(wave_sum(dd.x), wave_sum(dd.y), wave_sum(dd.z));
+    float sn = sqrtf(sw.x * sw.x + sw.y * sw.y + sw.z * sw.z);
+    bad = bad || !(sn > 1e-3f) || !(P.rho < 1e30f);
+    float inv = 1.0f / fmaxf(sn, 1e-3f);
+    P.w = f3(sw.x * inv, sw.y * inv, sw.z * inv);
+    float c = wave_min(P.w.x * dd.x + P.w.y * dd.y + P.w.z * dd.z) - 4e-6f;  // cos(theta), rounded down
+    bad = bad || !(c > 0.35f);
+    c = fminf(c, 1.0f);
+    float sT = sqrtf(fmaxf(0.0f, 1.0f - c * c)) + 4e-6f;
+    // widen by the filter's own angular tolerance (3.47e-3 rad) plus slack: E = 3.7e-3 rad
+    const float cosE = 0.99999316f, sinE = 3.7e-3f;
+    float cT = c * cosE - sT * sinE - 4e-6f;           // cos(theta + E), rounded down
+    float sT2 = sT * cosE + c * sinE + 4e-6f;          // sin(theta + E), rounded up
+    bad = bad || !(cT > 0.3f);
+    P.cosT2 = cT * cT;
+    P.sinT = sT2;
+    P.ok = !bad;
+    return P;
+}
+
+// true: the primitive may pass some lane's filter.  b = { c.xyz, -R^2 }.
+__device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
+{
+    float Cx = b.x - P.co.x, Cy = b.y - P.co.y, Cz = b.z - P.co.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;              // rounded down (cancellation, |w| != 1)
+    float Rp = (sqrtf(-b.w) * 1.00001f + P.rho) * 1.00001f + 1e-20f;
+    float rhs = Rp + a * P.sinT;
+    return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // NaN (R = inf, never-bounded primitives) passes
+}
+
+__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = base + threadIdx.x;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
+    F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
+    F3 nd = normalized(d);
+    const bool abn = ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(accinit));
+    HitAcc h;
+    h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
+    const Packet P = make_packet(o, nd, live, abn);
+    const int nprim = S.ns + S.nt;
+    for (int t0 = 0; t0 < nprim; t0 += kTile) {
+        __syncthreads();
+        const int cnt = stage_tile(tile, S.bounds, t0, nprim);
+        __syncthreads();
+        if (P.ok) {  // wave-uniform
+            for (int sub = 0; sub < cnt; sub += 64) {
+                float4 mine = tile[min(sub + lane, kTile - 1)];
+                unsigned long long mask = __ballot((sub + lane < cnt) && packet_test(P, mine));
+                if (__popcll(mask) > kPacketDense) {
+                    const int bend = min(sub + 64, cnt);
+                    for (int g = sub; g < bend; g += kGroup) {
+                        unsigned acc = accinit;
+#pragma unroll
+                        for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
+                        if ((int)acc >= 0) {
+                            int gend = min(kGroup, cnt - g);
+                            for (int u = 0; u < gend; u++)
+                                if (live && !(filt(fo, fd, tile[g + u]) < 0.0f)) exact_closest(S, t0 + g + u, o, d, nd, h);
+                        }
+                    }
+                } else {
+                    while (mask) {
+                        const int j = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        float4 b = tile[sub + j];
+                        if (live && !(filt(fo, fd, b) < 0.0f)) exact_closest(S, t0 + sub + j, o, d, nd, h);
+                    }
+                }
+            }
+        } else {
+            for (int g = 0; g < cnt; g += kGroup) {
+                unsigned acc = accinit;
+#pragma unroll
+                for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
+                if ((int)acc >= 0) {
+                    int gend = min(kGroup, cnt - g);
+                    for (int u = 0; u < gend; u++)
+                        if (live && (abn || !(filt(fo, fd, tile[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h);
+                }
+            }
+        }
+    }
+    if (live) {
+        L.t[i] = h.nearest;
+        L.prim[i] = (h.best < 0) ? -1 : (h.best | h.tflag);
+    }
+}
+
 
 // Thin generations (deep bounces: few, incoherent rays).  A workgroup takes only 64 rays and its
 // four waves split the primitive list into four contiguous slices, so a generation of a few
@@ -448,14 +582,10 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 {
     __shared__ float4 tile[kTile];
     const int n = *nrays;
-    if (n > kSmallRays) {
-        const int base = blockIdx.x * (kBlock * 2);
-        if (base >= n) return;  // block-uniform
-        closest_body<2>(S, L, n, base, tile);
-    } else if (n > kThinRays) {
+    if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
-        if (base >= n) return;
-        closest_body<1>(S, L, n, base, tile);
+        if (base >= n) return;  // block-uniform
+        closest_packet(S, L, n, base, tile);
     } else {
         if (blockIdx.x * 64 >= n) return;
         closest_thin(S, L, n, tile);
@@ -585,6 +715,102 @@ __device__ __forceinline__ void shadow_pass_body(const SceneDev& S, const Shadow
     }
 }
 
+// One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
+__device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n, const int base,
+                                                   const int c0, const int c1, int* cnt_out, unsigned char* lit, float4* tile)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = base + threadIdx.x;
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
+    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+    const int id = Qi.id[ii];
+    F3 nld = normalized(ld);
+    const bool abn = ray_abnormal(o, ld, nld, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(accinit));
+    bool done = !live;
+    const Packet P = make_packet(o, nld, live, abn);
+    for (int t0 = c0; t0 < c1; t0 += kTile) {
+        if (__syncthreads_and(done)) break;  // every ray of the workgroup is blocked
+        const int cnt = stage_tile(tile, S.sbounds, t0, c1);
+        __syncthreads();
+        if (__all(done)) continue;
+        if (P.ok) {
+            for (int sub = 0; sub < cnt; sub += 64) {
+                float4 mine = tile[min(sub + lane, kTile - 1)];
+                unsigned long long mask = __ballot((sub + lane < cnt) && packet_test(P, mine));
+                if (__popcll(mask) > kPacketDense) {
+                    // the packet keeps most of this batch: the grouped loop is cheaper than 64 single steps
+                    const int bend = min(sub + 64, cnt);
+                    for (int g = sub; g < bend; g += kGroup) {
+                        unsigned acc = accinit;
+#pragma unroll
+                        for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
+                        if ((int)acc >= 0) {
+                            int gend = min(kGroup, cnt - g);
+                            for (int u = 0; u < gend; u++)
+                                if (!done && !(filt(fo, fd, tile[g + u]) < 0.0f)) {
+                                    if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
+                                        done = true;
+                                        fo = f3(1e18f, 0.0f, 0.0f);
+                                        fd = f3(0.0f, 0.0f, 0.0f);
+                                    }
+                                }
+                        }
+                    }
+                } else {
+                    while (mask) {
+                        const int j = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        float4 b = tile[sub + j];
+                        if (!done && !(filt(fo, fd, b) < 0.0f)) {
+                            if (exact_any(S, S.sorder[t0 + sub + j], o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+        } else {
+            for (int g = 0; g < cnt; g += kGroup) {
+                unsigned acc = accinit;
+#pragma unroll
+                for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
+                if ((int)acc >= 0) {
+                    int gend = min(kGroup, cnt - g);
+                    for (int u = 0; u < gend; u++)
+                        if (!done && (abn || !(filt(fo, fd, tile[g + u]) < 0.0f))) {
+                            if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                                accinit = 0xFFFFFFFFu;
+                                asm volatile("" : "+v"(accinit));
+                            }
+                        }
+                }
+            }
+        }
+    }
+    const bool survive = live && !done;
+    const int slot = wave_alloc(survive, cnt_out);
+    if (survive) {
+        Qo.ox[slot] = o.x; Qo.oy[slot] = o.y; Qo.oz[slot] = o.z;
+        Qo.dx[slot] = ld.x; Qo.dy[slot] = ld.y; Qo.dz[slot] = ld.z;
+        Qo.id[slot] = id;
+    } else if (live) {
+        lit[id] = 0;
+    }
+}
+
 // Thin-generation form of a shadow pass: 64 rays per workgroup, the pass's chunk split over the
 // four waves; a ray is blocked if any wave found a blocker (any-hit: plain OR).
 __device__ __forceinline__ void shadow_pass_thin(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n,
@@ -657,14 +883,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
 {
     __shared__ float4 tile[kTile];
     const int n = *cnt_in;
-    if (n > kSmallRays) {
-        const int base = blockIdx.x * (kBlock * 2);
-        if (base >= n) return;  // block-uniform
-        shadow_pass_body<2>(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, tile);
-    } else if (n > kThinRays) {
+    if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
-        if (base >= n) return;
-        shadow_pass_body<1>(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, tile);
+        if (base >= n) return;  // block-uniform
+        shadow_pass_packet(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, tile);
     } else {
         if (blockIdx.x * 64 >= n) return;
         shadow_pass_thin(S, Qi, Qo, n, c0, c1, cnt_out, lit, tile);
