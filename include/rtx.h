@@ -101,6 +101,7 @@ typedef struct rtx_params {
                                    (ray, primitive) pair.  Must give the identical image; used to check that. */
 #define RTX_F_NO_HALO       8u  /* accounting only: trace the owned rows without the one-row halo and skip the
                                    antialias step (framebuffer undefined).  Gives a rank's UNIQUE ray counts. */
+#define RTX_F_PACKET_STATS 16u  /* fill rtx_stats.packet_stats (adds atomics to the intersection kernels: slower) */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
                                    exact ray x primitive tests executed, by kind -> rtx_stats.tests_*_kind */
 
@@ -128,6 +129,10 @@ typedef struct rtx_stats {
     float    ms_total;          /* device time of the last render, HIP events on its stream */
     float    ms_closest;        /* RTX_F_TIME_KERNELS only: summed device time of the closest-hit launches */
     float    ms_shadow;         /*                          ... of the shadow any-hit launches */
+    /* packet test: {waves, waves using it, 64-primitive batches tested, primitives kept} for the
+     * closest-hit kernel, then the same four for the shadow passes (non-thin generations only);
+     * RTX_F_PACKET_STATS only */
+    uint64_t packet_stats[8];
     int32_t  launches_closest;  /* launches behind ms_closest / ms_shadow */
     int32_t  launches_shadow;
 } rtx_stats;

@@ -12,6 +12,7 @@ F_TIME_KERNELS = 1
 F_COUNT_TESTS = 2
 F_EXACT_ONLY = 4
 F_NO_HALO = 8
+F_PACKET_STATS = 16
 
 
 class RtxError(RuntimeError):
@@ -80,6 +81,7 @@ class Stats(C.Structure):
                 ("tests_closest_kind", C.c_uint64 * 4), ("tests_shadow_kind", C.c_uint64 * 4),
                 ("singular_matrices", C.c_uint64), ("chunks", C.c_int32), ("levels", C.c_int32),
                 ("ms_total", C.c_float), ("ms_closest", C.c_float), ("ms_shadow", C.c_float),
+                ("packet_stats", C.c_uint64 * 8),
                 ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32)]
 
     @property
