@@ -682,32 +682,74 @@ __global__ __launch_bounds__(kBlock) void k_shadow_bin(SceneDev S, LevelDev L, c
     const int n = *nnodes;
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const int li = blockIdx.y;
-    if (j >= n) return;
-    ShadowRay r = make_shadow_ray(S, L, j, li, G);
-    rank[li * n + j] = atomicAdd(hist + r.key, 1);
-    L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
+    const bool live = j < n;
+    int key = -1;
+    if (live) {
+        key = make_shadow_ray(S, L, j, li, G).key;
+        L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
+    }
+    // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key
+    // per wave (leader election on the first pending lane's key) instead of one per ray.
+    int myrank = 0;
+    unsigned long long pending = __ballot(live);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(live && key == k0) & pending;
+        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
+        base = __shfl(base, leader);
+        if (live && key == k0 && ((same >> (threadIdx.x & 63)) & 1ull)) myrank = base + prefix;
+        pending &= ~same;
+    }
+    if (live) rank[li * n + j] = myrank;
 }
 
-// exclusive scan of the bin counts (one workgroup; a few hundred thousand bins at most)
-__global__ __launch_bounds__(1024) void k_shadow_scan(const int* hist, int* offs, int nbins, int* qcount)
+// Exclusive scan of the bin counts in three small launches: per-block scan of 1024 bins, scan of the
+// block sums, add-back.  nbins <= 4 Mi, so at most 4096 block sums.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int* hist, int* offs, int nbins, int* bsum)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x, b = blockIdx.x * 1024 + t;
+    const int v = (b < nbins) ? hist[b] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int x = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if (b < nbins) offs[b] = part[t] - v;
+    if (t == 1023) bsum[blockIdx.x] = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int* qcount)
 {
     __shared__ int part[1024];
     const int t = threadIdx.x;
-    const int per = (nbins + 1023) / 1024;
-    const int b0 = min(t * per, nbins), b1 = min(b0 + per, nbins);
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = min(t * per, nblocks), b1 = min(b0 + per, nblocks);
     int sum = 0;
-    for (int b = b0; b < b1; b++) sum += hist[b];
+    for (int b = b0; b < b1; b++) sum += bsum[b];
     part[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        int v = (t >= off) ? part[t - off] : 0;
+        int x = (t >= off) ? part[t - off] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
     int run = part[t] - sum;
-    for (int b = b0; b < b1; b++) { offs[b] = run; run += hist[b]; }
+    for (int b = b0; b < b1; b++) { int v = bsum[b]; bsum[b] = run; run += v; }
     if (t == 1023) *qcount = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum)
+{
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    if (b < nbins) offs[b] += bsum[blockIdx.x];
 }
 
 __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev L, const int* nnodes, int G, const int* offs,
@@ -1330,7 +1372,7 @@ struct rtx_context {
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
     ShadowQ sq[2] = {};                     // ping-pong shadow-ray queues
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
-    int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr;
+    int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr; int* d_bsum = nullptr;
     unsigned long long* d_pstat = nullptr;
     std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
     int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
@@ -1531,6 +1573,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&c->d_hist, (size_t)c->nbins))) return rc;
         if ((rc = c->dalloc(&c->d_offs, (size_t)c->nbins))) return rc;
         if ((rc = c->dalloc(&c->d_rank, qcap))) return rc;
+        if ((rc = c->dalloc(&c->d_bsum, (size_t)(c->nbins + 1023) / 1024))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->scnt_stride = (int)c->sched.size() + 1;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride))) return rc;
@@ -1599,7 +1642,12 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k) * c->scnt_stride;
                 HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)c->nbins, st));
                 hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_hist, c->d_rank);
-                hipLaunchKernelGGL(k_shadow_scan, dim3(1), dim3(1024), 0, st, c->d_hist, c->d_offs, c->nbins, sc + 0);
+                {
+                    const int nb = (c->nbins + 1023) / 1024;
+                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, c->nbins, c->d_bsum);
+                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, sc + 0);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, c->nbins, c->d_bsum);
+                }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_offs, c->d_rank, c->sq[0]);
                 unsigned gq = grid_for_isect(live_cap * (size_t)c->S.nl);
                 const int npass = (int)c->sched.size() - 1;
