@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -65,6 +66,7 @@ struct SceneDev {
     const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern (affine spheres never pass)
     const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
     int naff;
+    F3 box_lo, box_inv;           // scene box for ray binning: cell = (o - box_lo) * box_inv, 16 cells per axis
     unsigned long long* pstat;    // [8] packet statistics: closest {waves, waves ok, batches, survivors}, shadow {same}
     const float4* sbounds;        // [nsb] shadow-ordered filter records (no affine spheres), big occluders first
     const int* sorder;            // [nsb] primitive index of each
@@ -120,6 +122,25 @@ __device__ __forceinline__ int wave_alloc(bool want, int* counter)
     if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, __popcll(m));
     base = __shfl(base, leader);
     return want ? base + prefix : -1;
+}
+
+// The same for a whole 256-thread workgroup: slots keep the threads' order and the shared counter
+// takes one atomic per workgroup (same-address atomics cost ~5-12 ns each on this chip; a 4K frame's
+// set-up kernel issues 130,000 wave-level ones per queue otherwise).
+__device__ __forceinline__ int block_alloc(bool want, int* counter, int* sh)
+{
+    unsigned long long m = __ballot(want);
+    int lp = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int k = 0; k < kBlock / 64; k++) { if (k < w) woff += sh[k]; tot += sh[k]; }
+    if (threadIdx.x == 0) sh[4] = tot ? atomicAdd(counter, tot) : 0;
+    __syncthreads();
+    const int base = sh[4];
+    __syncthreads();
+    return want ? base + woff + lp : -1;
 }
 
 // Test counters (RTX_F_COUNT_TESTS): per-lane tallies, summed over the wave, one atomic per wave
@@ -443,12 +464,14 @@ __device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
     return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // NaN (R = inf, never-bounded primitives) passes
 }
 
-__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
+__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
 {
     const int lane = threadIdx.x & 63;
-    const int i = base + threadIdx.x;
-    const bool live = i < n;
-    const int ii = live ? i : 0;
+    const int q = base + threadIdx.x;
+    const bool live = q < n;
+    // secondary generations are traced in binned order (k_ray_bin): perm maps sorted position -> ray slot
+    const int i = live ? (perm ? perm[q] : q) : 0;
+    const int ii = i;
     F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
     F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
     F3 nd = normalized(d);
@@ -594,14 +617,14 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
+__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
     __shared__ float4 tile[kTile];
     const int n = *nrays;
     if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;  // block-uniform
-        closest_packet(S, L, n, base, tile);
+        closest_packet(S, L, n, base, tile, perm);
     } else {
         if (blockIdx.x * 64 >= n) return;
         closest_thin(S, L, n, tile);
@@ -661,6 +684,65 @@ __device__ __forceinline__ int light_cell(F3 v, int G)
     int cx = (int)fminf(fmaxf((px * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
     int cy = (int)fminf(fmaxf((py * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
     return (int)(morton8((unsigned)cx) | (morton8((unsigned)cy) << 1));
+}
+
+
+// Secondary rays (reflection / refraction) of neighbouring pixels leave from different surfaces in
+// different directions.  Before a generation k >= 1 is traced its rays are counting-sorted by
+// (origin cell of a 16^3 grid over the scene box, 16 x 16 octahedral direction cell), Morton order,
+// and traced in that order through a permutation, so that a wave is again a packet with a small
+// origin sphere and a narrow cone.  Generations too thin for packet mode skip the sort.
+constexpr int kRayBins = 1 << 20;
+
+__device__ __forceinline__ unsigned morton3_4(unsigned x)  // 4 bits -> every third bit
+{
+    x &= 0xfu;
+    x = (x | (x << 4)) & 0x0c3u;
+    x = (x | (x << 2)) & 0x249u;
+    return x;
+}
+
+__device__ __forceinline__ int ray_key(const SceneDev& S, F3 o, F3 d)
+{
+    int cx = (int)fminf(fmaxf((o.x - S.box_lo.x) * S.box_inv.x, 0.0f), 15.0f);
+    int cy = (int)fminf(fmaxf((o.y - S.box_lo.y) * S.box_inv.y, 0.0f), 15.0f);
+    int cz = (int)fminf(fmaxf((o.z - S.box_lo.z) * S.box_inv.z, 0.0f), 15.0f);
+    unsigned oc = morton3_4((unsigned)cx) | (morton3_4((unsigned)cy) << 1) | (morton3_4((unsigned)cz) << 2);
+    return (int)((oc << 8) | (unsigned)light_cell(d, 16));
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_bin(SceneDev S, LevelDev L, const int* nrays, int* hist, int* rank)
+{
+    const int n = *nrays;
+    if (n <= kThinRays) return;  // thin generations are not traced in packet mode
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    int key = -1;
+    if (live) key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
+    int myrank = 0;
+    unsigned long long pending = __ballot(live);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(live && key == k0) & pending;
+        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
+        base = __shfl(base, leader);
+        if ((same >> (threadIdx.x & 63)) & 1ull) myrank = base + prefix;
+        pending &= ~same;
+    }
+    if (live) rank[i] = myrank;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_scatter(SceneDev S, LevelDev L, const int* nrays, const int* offs, const int* rank, int* perm)
+{
+    const int n = *nrays;
+    if (n <= kThinRays) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
+    perm[offs[key] + rank[i]] = i;
 }
 
 struct ShadowRay { F3 o, ld; int key; };
@@ -1114,7 +1196,8 @@ __global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelD
     if (live && !hit) {  // :436-438: background, no ambient
         L.val[3 * i + 0] = 0.4f; L.val[3 * i + 1] = 0.4f; L.val[3 * i + 2] = 0.4f;
     }
-    int node = wave_alloc(hit, nnodes);
+    __shared__ int sh_alloc[8];
+    int node = block_alloc(hit, nnodes, sh_alloc);
     bool want_refl = false, want_refr = false;
     F3 o = f3(0, 0, 0), d = o, normal = o, ip = o, rd = o;
     float fres = 0.0f, fratio = 0.0f, eta = 1.0f;
@@ -1176,8 +1259,8 @@ __global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelD
         if (hit) { L.n_crefl[node] = -1; L.n_crefr[node] = -1; }
         return;
     }
-    int crefl = wave_alloc(want_refl, nnext);
-    int crefr = wave_alloc(want_refr, nnext);
+    int crefl = block_alloc(want_refl, nnext, sh_alloc);
+    int crefr = block_alloc(want_refr, nnext, sh_alloc);
     if (hit) { L.n_crefl[node] = crefl; L.n_crefr[node] = crefr; }
     if (want_refl) {  // :464-468
         F3 r = f3(rd.x + 2.0f * fratio * normal.x, rd.y + 2.0f * fratio * normal.y, rd.z + 2.0f * fratio * normal.z);
@@ -1374,6 +1457,7 @@ struct rtx_context {
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
     int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr; int* d_bsum = nullptr;
     unsigned long long* d_pstat = nullptr;
+    int* d_perm = nullptr; int* d_dummy = nullptr;
     std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
     int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
     int scnt_stride = 0, nframe_chunks = 0;
@@ -1505,6 +1589,22 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->sched.push_back(0);
         if (c->S.nsb > 0) c->sched.push_back(c->S.nsb);
         c->S.guard = P.guard;
+        {   // scene box for ray binning: every finite bounding sphere, 16 cells per axis
+            float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+            for (const BoundSphere& b : P.bounds) {
+                if (!std::isfinite(b.neg_r2)) continue;
+                float r = std::sqrt(-b.neg_r2);
+                const float cc[3] = {b.cx, b.cy, b.cz};
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cc[a] - r); hi[a] = std::max(hi[a], cc[a] + r); }
+            }
+            float inv[3];
+            for (int a = 0; a < 3; a++) {
+                if (!(hi[a] > lo[a])) { lo[a] = 0.0f; hi[a] = 1.0f; }
+                inv[a] = 16.0f / (hi[a] - lo[a]);
+            }
+            c->S.box_lo = {lo[0], lo[1], lo[2]};
+            c->S.box_inv = {inv[0], inv[1], inv[2]};
+        }
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
         if ((rc = c->upload(&iy, P.imagey))) return rc;
@@ -1570,10 +1670,13 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->binG = 256;
         while ((size_t)std::max(c->S.nl, 1) * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
         c->nbins = std::max(c->S.nl, 1) * c->binG * c->binG;
-        if ((rc = c->dalloc(&c->d_hist, (size_t)c->nbins))) return rc;
-        if ((rc = c->dalloc(&c->d_offs, (size_t)c->nbins))) return rc;
+        const size_t maxbins = std::max<size_t>((size_t)c->nbins, (size_t)kRayBins);
+        if ((rc = c->dalloc(&c->d_hist, maxbins))) return rc;
+        if ((rc = c->dalloc(&c->d_offs, maxbins))) return rc;
         if ((rc = c->dalloc(&c->d_rank, qcap))) return rc;
-        if ((rc = c->dalloc(&c->d_bsum, (size_t)(c->nbins + 1023) / 1024))) return rc;
+        if ((rc = c->dalloc(&c->d_bsum, (maxbins + 1023) / 1024))) return rc;
+        if ((rc = c->dalloc(&c->d_perm, (size_t)c->L[levels - 1].cap))) return rc;
+        if ((rc = c->dalloc(&c->d_dummy, (size_t)1))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->scnt_stride = (int)c->sched.size() + 1;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride))) return rc;
@@ -1625,10 +1728,22 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             bound[k] = live_cap;
             int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             unsigned g = grid_for(live_cap);
+            const int* perm = nullptr;
+            if (k > 0 && !count && !exact_only) {
+                // bin the secondary rays by (origin cell, direction cell) so that waves are coherent packets
+                HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)kRayBins, st));
+                hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_hist, c->d_rank);
+                const int nb = kRayBins / 1024;
+                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, kRayBins, c->d_bsum);
+                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, c->d_dummy);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, kRayBins, c->d_bsum);
+                hipLaunchKernelGGL(k_ray_scatter, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_offs, c->d_rank, c->d_perm);
+                perm = c->d_perm;
+            }
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
