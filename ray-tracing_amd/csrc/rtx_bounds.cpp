@@ -13,6 +13,11 @@
 //   Rays the analysis does not cover (non-finite or huge origin, direction not unit, a direction
 //   component in (0, 1e-10)) bypass the filter in the kernel ("abnormal" lanes).  Primitives it
 //   does not cover get R2 = +inf here and always pass.
+//   A direction of exactly zero IS covered: the reference's normalize leaves it zero, a plain sphere
+//   then accepts iff fl(|X|^2 - r^2) <= 0 (b = 0, disc = -4c, t1 = sqrt(disc)/2 >= 0), an affine
+//   sphere without translation row the same in object space (its world-space bound contains the
+//   ellipsoid), a triangle never (vd == 0); the filter with fd = 0 computes R2 - |X|^2 with R2 >=
+//   r^2 (1 + 2^-14), so every accepted origin passes.
 //
 // Margins (u = 2^-24):
 //   * evaluation error of F in binary32 FMA arithmetic: <= 8u (2|X|^2 + R2); the exact sphere

@@ -72,6 +72,11 @@ struct SceneDev {
     const int* sorder;            // [nsb] primitive index of each
     int nsb;
     float guard;                  // |origin component| beyond this: the ray bypasses the filter
+    // two-level packet test (rtx_pack.h, ClusterSet): cluster spheres, their 64 members, member -> primitive
+    const float4* ccl; const float4* cmem; const int* cidx; const int* cseg; int cnseg;  // closest-hit, per segment
+    const int* corder; int cnfirst;  // per-ray traversal order of the closest-hit clusters: affine-sphere clusters first
+    const float4* cclR; const float4* csubR;  // { c, R } cluster spheres [ncl] and 8 sub-cluster spheres each [ncl*8]
+    const float4* scl; const float4* smem; const int* sidx; int sncl;                    // shadow rays
 };
 
 struct CamDev {
@@ -275,9 +280,15 @@ __device__ __forceinline__ bool ray_abnormal(F3 o, F3 d, F3 nd, float guard)
 {
     bool ok = finite3(o) && finite3(d) && finite3(nd);
     float n2 = nd.x * nd.x + nd.y * nd.y + nd.z * nd.z;
-    ok = ok && (fabsf(n2 - 1.0f) <= 1e-3f);
-    ok = ok && (fabsf(d.x - nd.x) <= 1e-5f) && (fabsf(d.y - nd.y) <= 1e-5f) && (fabsf(d.z - nd.z) <= 1e-5f);
-    ok = ok && !(tiny_comp(d.x) || tiny_comp(d.y) || tiny_comp(d.z) || tiny_comp(nd.x) || tiny_comp(nd.y) || tiny_comp(nd.z));
+    bool dir = (fabsf(n2 - 1.0f) <= 1e-3f);
+    dir = dir && (fabsf(d.x - nd.x) <= 1e-5f) && (fabsf(d.y - nd.y) <= 1e-5f) && (fabsf(d.z - nd.z) <= 1e-5f);
+    dir = dir && !(tiny_comp(d.x) || tiny_comp(d.y) || tiny_comp(d.z) || tiny_comp(nd.x) || tiny_comp(nd.y) || tiny_comp(nd.z));
+    // A direction of exactly (0,0,0) -- what the reference's normalize (:116-125) leaves behind when a
+    // singular sphere matrix has flattened the incoming ray -- is a POINT: with fd = 0 the filter
+    // reads R^2 - |X|^2 >= 0, "the origin lies inside the bounding sphere", which is what the exact
+    // tests need too (sphere: b = 0, disc = -4c >= 0; triangle: vd == 0 rejects) -- rtx_bounds.cpp.
+    dir = dir || (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+    ok = ok && dir;
     ok = ok && (fabsf(o.x) <= guard) && (fabsf(o.y) <= guard) && (fabsf(o.z) <= guard);
     return !ok;
 }
@@ -464,6 +475,24 @@ __device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
     return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // NaN (R = inf, never-bounded primitives) passes
 }
 
+// The same test for ONE ray (origin o, unit or zero direction n): can the sphere b = { c, R } contain
+// the bounding sphere of a primitive whose filter passes for this ray?  The filter's pass region lies
+// inside { c : dist(c, double cone(o, +-n, E)) <= R_prim } (above), so a sphere around such primitives
+// passes if its centre is within its radius of that cone.  Returns the slack, sign bit clear = pass
+// (R = +inf gives +inf).  Used on cluster and sub-cluster spheres by the per-ray traversal; the plain
+// filter is NOT valid on enclosing spheres: its hyperboloid lacks the cone's cross term 2 R a tan(E).
+__device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
+{
+    const float cosE2 = 0.9999783f;  // (cos(3.7e-3) - 4e-6)^2 rounded down
+    const float sinE = 3.705e-3f;    // sin(3.7e-3) rounded up, + 4e-6
+    float Cx = b.x - o.x, Cy = b.y - o.y, Cz = b.z - o.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(n.x * Cx + n.y * Cy + n.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;
+    float rhs = (b.w * 1.00001f + 1e-20f) + a * sinE;
+    return rhs * rhs * 1.00001f - h2 * cosE2;
+}
+
 __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
 {
     const int lane = threadIdx.x & 63;
@@ -486,48 +515,54 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     const Packet P = make_packet(o, nd, live, abn);
     int pk_batches = 0, pk_surv = 0;
     const int nprim = S.ns + S.nt;
-    for (int t0 = 0; t0 < nprim; t0 += kTile) {
-        __syncthreads();
-        const int cnt = stage_tile(tile, S.bounds, t0, nprim);
-        __syncthreads();
+    // this wave's bitmap of candidate primitives of the current segment (wave-private LDS: the wave's
+    // DS operations execute in issue order, the fences only pin the compiler's ordering)
+    volatile unsigned* bm = reinterpret_cast<volatile unsigned*>(tile) + (threadIdx.x >> 6) * (kSegPrims / 32);
+    for (int seg = 0; seg < S.cnseg; seg++) {
+        const int p0 = seg * kSegPrims;
+        const int pn = min(kSegPrims, nprim - p0);
+        const int words = (pn + 31) >> 5;
         if (P.ok) {  // wave-uniform
-            for (int sub = 0; sub < cnt; sub += 64) {
-                float4 mine = tile[min(sub + lane, kTile - 1)];
-                unsigned long long mask = __ballot((sub + lane < cnt) && packet_test(P, mine));
-                pk_batches++; pk_surv += __popcll(mask);
-                if (__popcll(mask) > kPacketDense) {
-                    const int bend = min(sub + 64, cnt);
-                    for (int g = sub; g < bend; g += kGroup) {
-                        unsigned acc = accinit;
-#pragma unroll
-                        for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
-                        if ((int)acc >= 0) {
-                            int gend = min(kGroup, cnt - g);
-                            for (int u = 0; u < gend; u++)
-                                if (live && !(filt(fo, fd, tile[g + u]) < 0.0f)) exact_closest(S, t0 + g + u, o, d, nd, h);
-                        }
-                    }
-                } else {
-                    while (mask) {
-                        const int j = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        float4 b = tile[sub + j];
-                        if (live && !(filt(fo, fd, b) < 0.0f)) exact_closest(S, t0 + sub + j, o, d, nd, h);
-                    }
+            for (int j = lane; j < words; j += 64) bm[j] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const int c0 = S.cseg[seg], c1 = S.cseg[seg + 1];
+            for (int cb = c0; cb < c1; cb += 64) {
+                const int c = cb + lane;
+                unsigned long long cm = __ballot(c < c1 && packet_test(P, S.ccl[min(c, c1 - 1)]));
+                pk_batches++;
+                while (cm) {
+                    const int j = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    const size_t m = (size_t)(cb + j) * 64 + lane;
+                    const float4 mb = S.cmem[m];
+                    const int k = S.cidx[m];
+                    const bool pass = k >= 0 && packet_test(P, mb);
+                    if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
+                    pk_batches++; pk_surv += __popcll(__ballot(pass));
                 }
             }
         } else {
-            for (int g = 0; g < cnt; g += kGroup) {
-                unsigned acc = accinit;
-#pragma unroll
-                for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
-                if ((int)acc >= 0) {
-                    int gend = min(kGroup, cnt - g);
-                    for (int u = 0; u < gend; u++)
-                        if (live && (abn || !(filt(fo, fd, tile[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h);
+            for (int j = lane; j < words; j += 64) bm[j] = (j * 32 + 32 <= pn) ? 0xFFFFFFFFu : ((1u << (pn & 31)) - 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // walk the bitmap in index order: file order, as the reference's loops (:385-418)
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const unsigned wv = (w0 + lane < words) ? bm[w0 + lane] : 0u;
+            unsigned long long nz = __ballot(wv != 0u);
+            while (nz) {
+                const int j = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                unsigned bits = __builtin_amdgcn_readlane(wv, j);
+                while (bits) {
+                    const int bpos = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    const int k = p0 + ((w0 + j) << 5) + bpos;
+                    const float4 br = S.bounds[k];
+                    if (live && (abn || !(filt(fo, fd, br) < 0.0f))) exact_closest(S, k, o, d, nd, h);
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (S.pstat && lane == 0) {  // RTX_F_PACKET_STATS only: same-address atomics cost ~12 ns each
         atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, P.ok ? 1ull : 0ull);
@@ -539,6 +574,212 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     }
 }
 
+
+// Per-ray traversal of the cluster hierarchy, for the generations after the first: reflection and
+// refraction rays of neighbouring pixels leave curved surfaces in all directions, a wave of them is no
+// packet (measured on the benchmark scene: the packet test kept 1,171 of 10,000 primitives per wave at
+// level 1, against 17 at level 0).  Every LANE walks the hierarchy for its own ray instead:
+//   1. the filter against every cluster sphere (wave-uniform loop, 64 clusters per round, a bit per pass),
+//   2. lanes step through their own passing clusters in lockstep and run the filter against the 64
+//      members (per-lane gathers, sign bits AND-ed over groups of 8); members that pass are appended to
+//      the lane's candidate list in LDS,
+//   3. whenever a list is nearly full, and at the end, all lanes run the exact tests of their lists in
+//      lockstep.
+// The candidates of a ray arrive in cluster order, not file order, so the reference's sequential scan
+// (:385-418) is restated order-independently.  With H = the accepted hits (t_k, k):
+//   * nearest/best = the lexicographic minimum of (t_k, k) over hits with t_k < Max_t: the scan keeps
+//     the first of equal t's because it updates on strict `<` only;
+//   * a triangle that wins resets the `transformed` flag and only triangles follow it, so the flag is
+//     0 when best is a triangle; otherwise it is 1 iff some affine sphere k was a record when the scan
+//     reached it: t_k < Max_t and t_j > t_k for every hit j < k.  Affine-sphere clusters are traversed
+//     FIRST; their hits form a list in which (j < k, t_j <= t_k) removes k, and every later hit of a
+//     plain sphere removes entries the same way.  The flag is "list not empty".  The list holds the
+//     staircase of affine hits (index up, t down), 4 entries; a fifth sends the lane to the ordered
+//     scan over every primitive at the end (wave-uniform loop, only the flagged lanes active).
+// Rays the filter does not cover (ray_abnormal) take every cluster and every member.
+constexpr int kCandCap = 24;   // candidate list entries per lane (LDS)
+constexpr int kQBatch = 32;    // clusters per round; the lane's queue of passing clusters holds as many
+constexpr int kAffList = 4;
+
+constexpr int kLaneLds = kCandCap * 64 * 4 + kQBatch * 64 * 2;  // LDS bytes per wave: candidate lists + cluster queues
+
+struct LexAcc {
+    float nearest; int best;
+    float at[kAffList]; int ak[kAffList];
+    bool overflow;
+};
+
+// exact test of primitive k (per lane) with the order-independent update
+__device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
+{
+    if (k < S.ns) {
+        float4 hh = S.sph_hot[k];
+        int xf = S.sph_xf[k];
+        F3 to = o, td = nd;
+        if (xf) {
+            const rtx_xmatrix& im = S.sph_im[k];
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+            if (xf) {
+                if (t < kMaxT) {
+                    bool killed = false;
+#pragma unroll
+                    for (int e = 0; e < kAffList; e++) killed = killed || (h.ak[e] >= 0 && h.ak[e] < k && h.at[e] <= t);
+                    if (!killed) {
+                        bool placed = false;
+#pragma unroll
+                        for (int e = 0; e < kAffList; e++) {
+                            if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+                            if (!placed && h.ak[e] < 0) { h.ak[e] = k; h.at[e] = t; placed = true; }
+                        }
+                        if (!placed) h.overflow = true;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < kAffList; e++)
+                    if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+            }
+        }
+    } else {
+        TriRec T = load_tri(S.tri_hot, k - S.ns);
+        float t, vd;
+        if (triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+        }
+    }
+}
+
+__device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = base + threadIdx.x;
+    const bool live = q < n;
+    const int i = live ? (perm ? perm[q] : q) : 0;
+    F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
+    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    F3 nd = normalized(d);
+    const bool abn = live && ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    LexAcc h;
+    h.nearest = kMaxT; h.best = -1; h.overflow = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
+    int* cand = reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + lane;  // cand[slot * 64]
+    unsigned short* queue = reinterpret_cast<unsigned short*>(reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + kCandCap * 64) + lane;  // queue[slot * 64]
+    int ncand = 0, flushes = 0, tested = 0;
+    auto flush = [&]() {
+        const int maxn = (int)wave_max((float)ncand);
+        for (int a = 0; a < maxn; a++)
+            if (a < ncand) exact_lex(S, cand[a * 64], o, d, nd, h);
+        tested += ncand; flushes++;
+        ncand = 0;
+    };
+    const int ncl = S.cseg[S.cnseg];
+    for (int phase = 0; phase < 2; phase++) {
+        const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
+        for (int cb = cbeg; cb < cend; cb += kQBatch) {
+            // (1) this round's cluster spheres: one coalesced load, then lane u's record is broadcast
+            unsigned cmask = 0u;
+            const int ce = min(kQBatch, cend - cb);
+            const int myc = S.corder[min(cb + (lane & (kQBatch - 1)), cend - 1)];
+            const float4 mine = S.cclR[myc];
+            for (int u = 0; u < ce; u++) {
+                float4 b;
+                b.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), u));
+                b.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), u));
+                b.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), u));
+                b.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.w), u));
+                if (!(cone_slack(o, nd, b) < 0.0f)) cmask |= 1u << u;
+            }
+            if (abn) cmask = (ce == 32) ? ~0u : ((1u << ce) - 1u);
+            if (!live) cmask = 0u;
+            // (2) sub-cluster spheres of the lane's own passing clusters -> queue of (cluster slot, group mask)
+            int nq = 0;
+            while (__any(cmask != 0u)) {
+                const bool has = cmask != 0u;
+                const int u = has ? (__ffs(cmask) - 1) : 0;
+                cmask &= cmask - 1u;  // 0 stays 0
+                const int cid = __shfl(myc, u);
+                const float4* srec = S.csubR + (size_t)cid * 8;
+                unsigned gmask = 0u;
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+                    if (!(cone_slack(o, nd, srec[v]) < 0.0f)) gmask |= 1u << v;
+                if (abn) gmask = 0xFFu;
+                if (has && gmask) { queue[nq * 64] = (unsigned short)((u << 8) | gmask); nq++; }
+            }
+            // (3) the members of the lane's own passing groups, one group of 8 per step
+            int qi = 0, cid = 0;
+            unsigned gm = 0u;
+            while (true) {
+                const bool refill = gm == 0u && qi < nq;
+                const unsigned e = refill ? (unsigned)queue[qi * 64] : 0u;
+                const int cnext = __shfl(myc, (int)(e >> 8));  // every lane takes part: ds_bpermute reads 0 from inactive lanes
+                if (refill) { qi++; gm = e & 0xFFu; cid = cnext; }
+                if (!__any(gm != 0u)) break;
+                const bool hasg = gm != 0u;
+                const int g = hasg ? (__ffs(gm) - 1) : 0;
+                gm &= gm - 1u;
+                const float4* mrec = S.cmem + (size_t)cid * 64 + g * 8;
+                const int* midx = S.cidx + (size_t)cid * 64 + g * 8;
+                float4 mb[kGroup];
+#pragma unroll
+                for (int v = 0; v < kGroup; v++) mb[v] = mrec[v];
+                unsigned acc = 0xFFFFFFFFu;
+#pragma unroll
+                for (int v = 0; v < kGroup; v++) acc &= __float_as_uint(filt(fo, fd, mb[v]));
+                if (hasg && (abn || (int)acc >= 0)) {
+#pragma unroll
+                    for (int v = 0; v < kGroup; v++) {
+                        if (abn || !(filt(fo, fd, mb[v]) < 0.0f)) {
+                            const int k = midx[v];
+                            if (k >= 0) { cand[ncand * 64] = k; ncand++; }
+                        }
+                    }
+                }
+                if (__any(ncand > kCandCap - kGroup)) flush();
+            }
+        }
+        flush();  // phase 0: every affine-sphere hit is known before the first plain sphere is tested
+    }
+    bool alive = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) alive = alive || h.ak[e] >= 0;
+    float nearest = h.nearest;
+    int best = h.best;
+    int tflag = (best >= 0 && best < S.ns && alive) ? kTFlag : 0;
+    const bool slow = live && h.overflow;
+    if (__any(slow)) {
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        const int nprim = S.ns + S.nt;
+        for (int k = 0; k < nprim; k++) {
+            const float4 b = S.bounds[k];
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
+        }
+        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+    }
+    if (S.pstat) {
+        const unsigned long long sl = __ballot(slow);
+        const unsigned long long ab = __ballot(abn);
+        const float tot = wave_sum(live ? (float)tested : 0.0f);
+        if (lane == 0) {
+            atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, (unsigned long long)__popcll(sl) + ((unsigned long long)__popcll(ab) << 32));
+            atomicAdd(S.pstat + 2, (unsigned long long)flushes); atomicAdd(S.pstat + 3, (unsigned long long)tot);
+        }
+    }
+    if (live) {
+        L.t[i] = nearest;
+        L.prim[i] = (best < 0) ? -1 : (best | tflag);
+    }
+}
 
 // Thin generations (deep bounces: few, incoherent rays).  A workgroup takes only 64 rays and its
 // four waves split the primitive list into four contiguous slices, so a generation of a few
@@ -619,7 +860,7 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
 
 __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
-    __shared__ float4 tile[kTile];
+    __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps
     const int n = *nrays;
     if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
@@ -629,6 +870,15 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
         if (blockIdx.x * 64 >= n) return;
         closest_thin(S, L, n, tile);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
+{
+    __shared__ float4 tile[kLaneLds * (kBlock / 64) / 16];  // the four waves' candidate lists and cluster queues (40 KiB)
+    const int n = *nrays;
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    closest_lanes(S, L, n, base, tile, n > kThinRays ? perm : nullptr);
 }
 
 // exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
@@ -955,69 +1205,56 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     if (one_light) apex = f3(S.lights[li0].point);
     const Packet P = make_packet(o, nld, live, abn, one_light, apex);
     int pk_batches = 0, pk_surv = 0;
-    for (int t0 = c0; t0 < c1; t0 += kTile) {
-        if (__syncthreads_and(done)) break;  // every ray of the workgroup is blocked
-        const int cnt = stage_tile(tile, S.sbounds, t0, c1);
-        __syncthreads();
-        if (__all(done)) continue;
-        if (P.ok) {
-            for (int sub = 0; sub < cnt; sub += 64) {
-                float4 mine = tile[min(sub + lane, kTile - 1)];
-                unsigned long long mask = __ballot((sub + lane < cnt) && packet_test(P, mine));
-                pk_batches++; pk_surv += __popcll(mask);
-                if (__popcll(mask) > kPacketDense) {
-                    // the packet keeps most of this batch: the grouped loop is cheaper than 64 single steps
-                    const int bend = min(sub + 64, cnt);
-                    for (int g = sub; g < bend; g += kGroup) {
-                        unsigned acc = accinit;
-#pragma unroll
-                        for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
-                        if ((int)acc >= 0) {
-                            int gend = min(kGroup, cnt - g);
-                            for (int u = 0; u < gend; u++)
-                                if (!done && !(filt(fo, fd, tile[g + u]) < 0.0f)) {
-                                    if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
-                                        done = true;
-                                        fo = f3(1e18f, 0.0f, 0.0f);
-                                        fd = f3(0.0f, 0.0f, 0.0f);
-                                    }
-                                }
-                        }
-                    }
-                } else {
-                    while (mask) {
-                        const int j = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        float4 b = tile[sub + j];
-                        if (!done && !(filt(fo, fd, b) < 0.0f)) {
-                            if (exact_any(S, S.sorder[t0 + sub + j], o, ld, nld)) {
-                                done = true;
-                                fo = f3(1e18f, 0.0f, 0.0f);
-                                fd = f3(0.0f, 0.0f, 0.0f);
-                            }
+    if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
+        bool out = __all(done);
+        for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+            const int c = cb + lane;
+            unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+            pk_batches++;
+            while (cm && !out) {
+                const int j = __ffsll((long long)cm) - 1;
+                cm &= cm - 1;
+                const size_t m = (size_t)(cb + j) * 64 + lane;
+                const float4 mb = S.smem[m];
+                const int k = S.sidx[m];
+                unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
+                pk_batches++; pk_surv += __popcll(mm);
+                while (mm) {
+                    const int u = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    float4 br;
+                    br.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.x), u));
+                    br.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.y), u));
+                    br.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.z), u));
+                    br.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.w), u));
+                    const int kk = __builtin_amdgcn_readlane(k, u);
+                    if (!done && !(filt(fo, fd, br) < 0.0f)) {
+                        if (exact_any(S, kk, o, ld, nld)) {
+                            done = true;
+                            fo = f3(1e18f, 0.0f, 0.0f);
+                            fd = f3(0.0f, 0.0f, 0.0f);
                         }
                     }
                 }
-                if (__all(done)) break;
+                out = __all(done);
             }
-        } else {
-            for (int g = 0; g < cnt; g += kGroup) {
-                unsigned acc = accinit;
-#pragma unroll
-                for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, tile[g + u]));
-                if ((int)acc >= 0) {
-                    int gend = min(kGroup, cnt - g);
-                    for (int u = 0; u < gend; u++)
-                        if (!done && (abn || !(filt(fo, fd, tile[g + u]) < 0.0f))) {
-                            if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
-                                done = true;
-                                fo = f3(1e18f, 0.0f, 0.0f);
-                                fd = f3(0.0f, 0.0f, 0.0f);
-                                accinit = 0xFFFFFFFFu;
-                                asm volatile("" : "+v"(accinit));
-                            }
+        }
+    } else {
+        for (int g = c0; g < c1 && !__all(done); g += kGroup) {
+            const int gend = min(kGroup, c1 - g);
+            unsigned acc = accinit;
+            for (int u = 0; u < gend; u++) acc &= __float_as_uint(filt(fo, fd, S.sbounds[g + u]));
+            if ((int)acc >= 0) {
+                for (int u = 0; u < gend; u++)
+                    if (!done && (abn || !(filt(fo, fd, S.sbounds[g + u]) < 0.0f))) {
+                        if (exact_any(S, S.sorder[g + u], o, ld, nld)) {
+                            done = true;
+                            fo = f3(1e18f, 0.0f, 0.0f);
+                            fd = f3(0.0f, 0.0f, 0.0f);
+                            accinit = 0xFFFFFFFFu;
+                            asm volatile("" : "+v"(accinit));
                         }
-                }
+                    }
             }
         }
     }
@@ -1589,6 +1826,34 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->sched.push_back(0);
         if (c->S.nsb > 0) c->sched.push_back(c->S.nsb);
         c->S.guard = P.guard;
+        {
+            auto up4 = [&](const std::vector<BoundSphere>& v, const float4** dst) -> int {
+                float4* q = nullptr;
+                int r = c->dalloc(&q, v.size());
+                if (r) return r;
+                if (!v.empty()) HIPCHK(hipMemcpy(q, v.data(), v.size() * sizeof(float4), hipMemcpyHostToDevice));
+                *dst = q;
+                return RTX_OK;
+            };
+            int* q = nullptr;
+            if ((rc = up4(P.cc.cl, &c->S.ccl))) return rc;
+            if ((rc = up4(P.cc.mem, &c->S.cmem))) return rc;
+            if ((rc = c->upload(&q, P.cc.idx))) return rc;
+            c->S.cidx = q;
+            if ((rc = c->upload(&q, P.cc.seg_first))) return rc;
+            c->S.cseg = q;
+            c->S.cnseg = (int)P.cc.seg_first.size() - 1;
+            if ((rc = up4(P.cc.clR, &c->S.cclR))) return rc;
+            if ((rc = up4(P.cc.subR, &c->S.csubR))) return rc;
+            if ((rc = c->upload(&q, P.cc.order))) return rc;
+            c->S.corder = q;
+            c->S.cnfirst = P.cc.nfirst;
+            if ((rc = up4(P.sc.cl, &c->S.scl))) return rc;
+            if ((rc = up4(P.sc.mem, &c->S.smem))) return rc;
+            if ((rc = c->upload(&q, P.sc.idx))) return rc;
+            c->S.sidx = q;
+            c->S.sncl = (int)P.sc.cl.size();
+        }
         {   // scene box for ray binning: every finite bounding sphere, 16 cells per axis
             float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
             for (const BoundSphere& b : P.bounds) {
@@ -1743,6 +2008,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
+            else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,

@@ -60,6 +60,130 @@ rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular)
     return r;
 }
 
+namespace {
+
+inline uint32_t spread10(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+struct Item { double c[3]; double R; uint32_t key; int32_t slot; };
+
+// one group of items -> clusters of <= 64 consecutive items in Morton order of their centres
+void emit_clusters(std::vector<Item>& items, bool bounded, const std::vector<BoundSphere>& rec,
+                   const std::vector<int32_t>& ids, ClusterSet& out)
+{
+    if (items.empty()) return;
+    if (bounded) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (const Item& it : items)
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], it.c[a]); hi[a] = std::max(hi[a], it.c[a]); }
+        for (Item& it : items) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++) {
+                double e = hi[a] - lo[a];
+                double f = e > 0 ? (it.c[a] - lo[a]) / e : 0.0;
+                q[a] = (uint32_t)std::min(1023.0, std::max(0.0, f * 1024.0));
+            }
+            it.key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+    }
+    const float inf = std::numeric_limits<float>::infinity();
+    // sphere around items [j0, j1): centre rounded to binary32 FIRST, radius measured from the rounded
+    // centre and rounded up; { c, R }.  Not bounded: { 0, 0, 0, +inf }.
+    auto enclose = [&](size_t j0, size_t j1) -> BoundSphere {
+        if (!bounded || j0 >= j1) return {0.0f, 0.0f, 0.0f, (j0 >= j1) ? 0.0f : inf};
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = j0; i < j1; i++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], items[i].c[a] - items[i].R);
+                hi[a] = std::max(hi[a], items[i].c[a] + items[i].R);
+            }
+        float cf[3];
+        for (int a = 0; a < 3; a++) cf[a] = (float)(0.5 * (lo[a] + hi[a]));
+        double R = 0.0;
+        for (size_t i = j0; i < j1; i++) {
+            double dx = items[i].c[0] - cf[0], dy = items[i].c[1] - cf[1], dz = items[i].c[2] - cf[2];
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + items[i].R);
+        }
+        float Rf = std::nextafter((float)(R * (1.0 + 1e-6)), inf);
+        if (!std::isfinite(Rf) || !(Rf < 1e15f) || !std::isfinite(cf[0]) || !std::isfinite(cf[1]) || !std::isfinite(cf[2]))
+            return {0.0f, 0.0f, 0.0f, inf};
+        return {cf[0], cf[1], cf[2], Rf};
+    };
+    for (size_t i0 = 0; i0 < items.size(); i0 += kClusterSize) {
+        size_t i1 = std::min(items.size(), i0 + kClusterSize);
+        BoundSphere cr = enclose(i0, i1);
+        BoundSphere cs = {0.0f, 0.0f, 0.0f, -inf};
+        if (std::isfinite(cr.neg_r2)) {
+            float nr2 = std::nextafter((float)(-((double)cr.neg_r2 * (double)cr.neg_r2)), -inf);
+            if (std::isfinite(nr2)) cs = {cr.cx, cr.cy, cr.cz, nr2};
+            else cr = {0.0f, 0.0f, 0.0f, inf};
+        }
+        out.cl.push_back(cs);
+        out.clR.push_back(cr);
+        for (size_t g = i0; g < i0 + kClusterSize; g += 8) out.subR.push_back(enclose(std::min(g, i1), std::min(g + 8, i1)));
+        for (size_t i = i0; i < i0 + kClusterSize; i++) {
+            if (i < i1) { out.mem.push_back(rec[items[i].slot]); out.idx.push_back(ids[items[i].slot]); }
+            else { out.mem.push_back({0.0f, 0.0f, 0.0f, inf}); out.idx.push_back(-1); }
+        }
+    }
+}
+
+}  // namespace
+
+void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32_t>& ids, int seg_prims,
+                    const std::vector<uint8_t>* cls, ClusterSet& out)
+{
+    out = ClusterSet();
+    const size_t n = rec.size();
+    int32_t maxid = -1;
+    for (int32_t v : ids) maxid = std::max(maxid, v);
+    const int nseg = (seg_prims > 0) ? std::max(1, (maxid + seg_prims) / seg_prims) : 1;
+    std::vector<uint8_t> cl_class;
+    for (int seg = 0; seg < nseg; seg++) {
+        out.seg_first.push_back((int32_t)out.cl.size());
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && !cls) break;
+            std::vector<Item> small, big, unb;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (size_t i = 0; i < n; i++) {
+                if (seg_prims > 0 && ids[i] / seg_prims != seg) continue;
+                if (cls && ((*cls)[i] != 0) != (pass == 1)) continue;
+                const BoundSphere& b = rec[i];
+                if (b.neg_r2 == std::numeric_limits<float>::infinity()) continue;  // can never pass: in no cluster
+                Item it = {{b.cx, b.cy, b.cz}, 0.0, 0u, (int32_t)i};
+                bool ok = std::isfinite(b.cx) && std::isfinite(b.cy) && std::isfinite(b.cz) && std::isfinite(b.neg_r2) && b.neg_r2 <= 0.0f;
+                if (!ok) { unb.push_back(it); continue; }
+                it.R = std::sqrt(-(double)b.neg_r2);
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], it.c[a]); hi[a] = std::max(hi[a], it.c[a]); }
+                small.push_back(it);
+            }
+            // primitives that are large against the cloud of centres would blow up their neighbours' cluster
+            double ext = 0.0;
+            for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
+            std::vector<Item> keep;
+            for (const Item& it : small) (it.R > 0.125 * ext && small.size() > (size_t)kClusterSize ? big : keep).push_back(it);
+            emit_clusters(keep, true, rec, ids, out);
+            emit_clusters(big, true, rec, ids, out);
+            emit_clusters(unb, false, rec, ids, out);
+            cl_class.resize(out.cl.size(), (uint8_t)pass);
+        }
+    }
+    for (int pass = 1; pass >= 0; pass--) {
+        for (size_t c = 0; c < cl_class.size(); c++)
+            if (cl_class[c] == pass) out.order.push_back((int32_t)c);
+        if (pass == 1) out.nfirst = (int32_t)out.order.size();
+    }
+    out.seg_first.push_back((int32_t)out.cl.size());
+}
+
 void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
 {
     P = PackedScene();
@@ -143,6 +267,15 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
         }
         std::stable_sort(w.begin(), w.end(), [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first > b.first; });
         for (auto& e : w) { P.sorder.push_back(e.second); P.sbounds.push_back(P.bounds[e.second]); }
+    }
+
+    {
+        std::vector<int32_t> all(P.bounds.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (int32_t)i;
+        std::vector<uint8_t> cls(P.bounds.size(), 0);
+        for (size_t i = 0; i < P.sph_xf.size(); i++) cls[i] = P.sph_xf[i] ? 1 : 0;
+        build_clusters(P.bounds, all, kSegPrims, &cls, P.cc);
+        build_clusters(P.sbounds, P.sorder, 0, nullptr, P.sc);
     }
 
     // camera basis, raytracing.cpp:725-737

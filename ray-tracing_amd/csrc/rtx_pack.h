@@ -42,7 +42,38 @@ BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard);
 struct AffineShadowRec { float ax, ay, az, bx, by, bz, cx, cy, cz, ox, oy, oz, neg_r2; int32_t index; float pad0, pad1; };
 AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im, int index);
 
+// Spatial clusters of up to 64 filter records each, for the two-level packet test (rtx_device.hip,
+// closest_packet / shadow_pass_packet): a wave first tests its packet against the CLUSTER spheres (one
+// cluster per lane), then against the 64 MEMBER spheres of every cluster that passed (one member per
+// lane).  A cluster sphere encloses its members' (already inflated) bounding spheres, so a member that
+// can pass some ray's filter implies a cluster that passes the packet test.  Members that cannot be
+// bounded (-R^2 = -inf or NaN: always pass) sit in clusters of their own whose record is -inf as well.
+// Closest-hit needs the primitives in FILE order (strict `<`, sticky flag), so its clusters are built
+// per segment of kSegPrims consecutive primitives and only mark bits in a per-wave bitmap that is then
+// walked in index order; shadow rays are any-hit and test members as they come.
+constexpr int kClusterSize = 64;
+constexpr int kSegPrims = 1 << 15;
+struct ClusterSet {
+    std::vector<BoundSphere> cl;        // [ncl]
+    std::vector<BoundSphere> mem;       // [ncl * 64], padding: idx = -1
+    std::vector<int32_t>     idx;       // [ncl * 64] primitive index (sphere i | ns + triangle i)
+    std::vector<int32_t>     seg_first; // [nseg + 1] cluster range of every segment
+    // per-ray traversal order (closest_lanes): clusters of affine spheres first (they never share a cluster
+    // with anything else), then the rest; nfirst = how many come first
+    std::vector<int32_t>     order;
+    int32_t                  nfirst = 0;
+    // the same hierarchy for the per-ray cone test (rtx_device.hip, cone_test): { c, R } with R >= 0 in
+    // the 4th component (+inf: always passes); clR [ncl] = the cluster spheres, subR [ncl * 8] = spheres
+    // around members 8g .. 8g+7 of each cluster
+    std::vector<BoundSphere> clR, subR;
+};
+// cls (optional, per record): records with a non-zero class are clustered apart from the others
+void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32_t>& ids, int seg_prims,
+                    const std::vector<uint8_t>* cls, ClusterSet& out);
+
 struct PackedScene {
+    ClusterSet cc;                            // closest-hit clusters over `bounds`, segmented
+    ClusterSet sc;                            // shadow clusters over `sbounds`, one segment
     std::vector<AffineShadowRec> aff_shadow;  // one per affine sphere, file order
     // Shadow rays are any-hit: the order primitives are tried in cannot change the result, only how
     // soon a blocked ray stops.  sbounds = filter records of every primitive except affine spheres,

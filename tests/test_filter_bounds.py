@@ -109,6 +109,35 @@ def test_filter_on_synthetic_c4(rt, oracle, tmp_path):
     assert P.mean() < 0.05
 
 
+def test_zero_direction_is_a_point_query(rt, oracle, tmp_path):
+    """Rays whose direction is exactly (0,0,0) (children of hits on spheres with a singular matrix) go
+    through the filter with fd = 0: it must keep every primitive the exact test accepts for them."""
+    p = tmp_path / "c4s.txt"
+    rt.scenegen.write_c4(str(p), nspheres=300, ntriangles=300)
+    sc = rt.load_scene(str(p))
+    rec, guard = rt.filter_records(sc)
+    rng = np.random.default_rng(5)
+    v = sc.view
+    pts = []
+    for i in range(v.nspheres):
+        s = v.spheres[i]
+        c = np.array([s.center.x, s.center.y, s.center.z])
+        u = rng.normal(size=(40, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        pts.append(c + u * abs(s.radius) * rng.choice([0.0, 0.5, 0.99999, 1.0, 1.00001, 1.2], size=(40, 1)))
+    for i in range(v.ntriangles):
+        t = v.triangles[i]
+        pts.append(np.array([[t.u.x, t.u.y, t.u.z], [t.v.x, t.v.y, t.v.z]]))
+    o = np.concatenate(pts).astype(f32)
+    d = np.zeros_like(o)
+    acc = oracle.accept_matrix(sc, o, d).astype(bool)
+    P = filter_pass(rec, o, d)
+    assert acc.sum() > 3000
+    assert not acc[:, v.nspheres:].any(), "a zero direction never hits a triangle (vd == 0)"
+    assert not (acc & ~P).any()
+    assert P.mean() < 0.05
+
+
 def test_degenerate_primitives_always_pass(rt, tmp_path):
     p = tmp_path / "deg.txt"
     p.write_text("5\ncamera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0 0 0\n"

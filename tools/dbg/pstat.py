@@ -4,10 +4,14 @@ import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
-W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-ctx = rt.Context(sc, rt.Params.make(W, H, 4, flags=rt.host.F_TIME_KERNELS | rt.host.F_PACKET_STATS))
-ctx.render(); st = ctx.stats()
-ps = list(st.packet_stats)
-print("frame ms", st.ms_total, "closest", st.ms_closest, "shadow", st.ms_shadow)
-print("closest: waves %d ok %d (%.1f%%) batches %d survivors %d (%.2f per batch)" % (ps[0], ps[1], 100.0*ps[1]/max(ps[0],1), ps[2], ps[3], ps[3]/max(ps[2],1)))
-print("shadow : waves %d ok %d (%.1f%%) batches %d survivors %d (%.2f per batch)" % (ps[4], ps[5], 100.0*ps[5]/max(ps[4],1), ps[6], ps[7], ps[7]/max(ps[6],1)))
+W, H = 3840, 2160
+prev = [0] * 8
+for md in (0, 1, 2, 3):
+    ctx = rt.Context(sc, rt.Params.make(W, H, md, flags=rt.host.F_TIME_KERNELS | rt.host.F_PACKET_STATS))
+    ctx.render(); st = ctx.stats()
+    ps = list(st.packet_stats)
+    d = [a - b for a, b in zip(ps, prev)]; prev = ps
+    print("level %d rays %d: frame ms %.2f" % (md, st.rays_level[md], st.ms_total))
+    print("  closest: waves %d ok %d (%.1f%%) batches/wave %.1f survivors/wave %.1f" % (d[0], d[1], 100.0*d[1]/max(d[0],1), d[2]/max(d[0],1), d[3]/max(d[0],1)))
+    print("  shadow : waves %d ok %d (%.1f%%) batches/wave %.1f survivors/wave %.1f" % (d[4], d[5], 100.0*d[5]/max(d[4],1), d[6]/max(d[4],1), d[7]/max(d[4],1)))
+    ctx.close()
