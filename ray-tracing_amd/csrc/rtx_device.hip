@@ -431,8 +431,12 @@ __device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, 
     bool bad = __any(live && abn) || lm == 0;
     int src = lm ? (__ffsll((long long)lm) - 1) : 0;
     // dead lanes borrow a live lane's ray so they do not widen the bounds
-    F3 oo = f3(live ? o.x : __shfl(o.x, src), live ? o.y : __shfl(o.y, src), live ? o.z : __shfl(o.z, src));
-    F3 dd = f3(live ? nd.x : __shfl(nd.x, src), live ? nd.y : __shfl(nd.y, src), live ? nd.z : __shfl(nd.z, src));
+    // (the shuffles are evaluated by EVERY lane, outside the selects: a ds_bpermute under a divergent branch
+    // reads 0 from the lanes that did not take the branch)
+    const F3 so = f3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+    const F3 sd = f3(__shfl(nd.x, src), __shfl(nd.y, src), __shfl(nd.z, src));
+    F3 oo = f3(live ? o.x : so.x, live ? o.y : so.y, live ? o.z : so.z);
+    F3 dd = f3(live ? nd.x : sd.x, live ? nd.y : sd.y, live ? nd.z : sd.z);
     float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
     P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
     float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
@@ -789,6 +793,7 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
 // `transformed` flag (:396-399) is set iff some slice's last affine-sphere record beats the minimum
 // of the slices before it.
 constexpr int kThinRays = 1 << 18;
+constexpr int kThinShadow = 1 << 14;  // shadow rays are light-binned packets at any population above this
 constexpr int kThinTile = kTile / 4;
 
 __device__ __forceinline__ int stage_thin(float4* mt, const float4* bounds, int t0, int end, int lane)
@@ -1040,7 +1045,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_bin(SceneDev S, LevelDev L, c
 
 // Exclusive scan of the bin counts in three small launches: per-block scan of 1024 bins, scan of the
 // block sums, add-back.  nbins <= 4 Mi, so at most 4096 block sums.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const int* hist, int* offs, int nbins, int* bsum)
+// align > 1 (shadow queues): every group of 1024 bins -- a 32 x 32 square of one light's direction map --
+// starts at a slot that is a multiple of `align` (64), so no wave straddles two lights or a long jump of
+// the Morton curve; the slots skipped are marked as padding (id = -1) by k_scan_add.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int* hist, int* offs, int nbins, int* bsum, int* braw, int align)
 {
     __shared__ int part[1024];
     const int t = threadIdx.x, b = blockIdx.x * 1024 + t;
@@ -1054,7 +1062,10 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const int* hist, int* offs
         __syncthreads();
     }
     if (b < nbins) offs[b] = part[t] - v;
-    if (t == 1023) bsum[blockIdx.x] = part[1023];
+    if (t == 1023) {
+        braw[blockIdx.x] = part[1023];
+        bsum[blockIdx.x] = (part[1023] + align - 1) / align * align;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int* qcount)
@@ -1078,10 +1089,16 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int*
     if (t == 1023) *qcount = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum)
+__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, int* pad_ids)
 {
     const int b = blockIdx.x * 1024 + threadIdx.x;
-    if (b < nbins) offs[b] += bsum[blockIdx.x];
+    const int start = bsum[blockIdx.x];
+    if (b < nbins) offs[b] += start;
+    if (pad_ids) {
+        const int raw = braw[blockIdx.x];
+        const int pad = (raw + align - 1) / align * align - raw;
+        if ((int)threadIdx.x < pad) pad_ids[start + raw + threadIdx.x] = -1;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev L, const int* nnodes, int G, const int* offs,
@@ -1197,69 +1214,98 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
     asm volatile("" : "+v"(accinit));
     bool done = !live;
-    // all live lanes aimed at the same light?  then their lines share that point
+    int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0;
+    auto bcast4 = [](float4 v, int u) {
+        float4 r;
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), u));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), u));
+        r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.z), u));
+        r.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.w), u));
+        return r;
+    };
+    // A wave is traced as ONE packet when its 64 rays make a usable one.  At a seam -- the last rays towards
+    // one light followed by the first towards the next, a jump of the Morton curve over the direction map,
+    // an abnormal ray -- they do not: the lanes are then split into aligned blocks of 32, 16, ... 1, each
+    // traced as a packet of its own with the other lanes switched off.  A single ray that makes no packet
+    // (an abnormal one) takes the transposed scan below.
     const int li = id / lit_cap;
-    const int li0 = __shfl(li, max(0, __ffsll((long long)__ballot(live)) - 1));
-    const bool one_light = __all(!live || li == li0) && li0 >= 0 && li0 < S.nl;
-    F3 apex = f3(0.0f, 0.0f, 0.0f);
-    if (one_light) apex = f3(S.lights[li0].point);
-    const Packet P = make_packet(o, nld, live, abn, one_light, apex);
-    int pk_batches = 0, pk_surv = 0;
-    if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
-        bool out = __all(done);
-        for (int cb = 0; cb < S.sncl && !out; cb += 64) {
-            const int c = cb + lane;
-            unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
-            pk_batches++;
-            while (cm && !out) {
-                const int j = __ffsll((long long)cm) - 1;
-                cm &= cm - 1;
-                const size_t m = (size_t)(cb + j) * 64 + lane;
-                const float4 mb = S.smem[m];
-                const int k = S.sidx[m];
-                unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
-                pk_batches++; pk_surv += __popcll(mm);
-                while (mm) {
-                    const int u = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    float4 br;
-                    br.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.x), u));
-                    br.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.y), u));
-                    br.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.z), u));
-                    br.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb.w), u));
-                    const int kk = __builtin_amdgcn_readlane(k, u);
-                    if (!done && !(filt(fo, fd, br) < 0.0f)) {
-                        if (exact_any(S, kk, o, ld, nld)) {
-                            done = true;
-                            fo = f3(1e18f, 0.0f, 0.0f);
-                            fd = f3(0.0f, 0.0f, 0.0f);
+    unsigned long long remaining = __ballot(live), fallback = 0ull;
+    int size = 64;
+    while (remaining) {
+        const int first = __ffsll((long long)remaining) - 1;
+        const int lo = first & ~(size - 1);
+        const unsigned long long blk = ((size == 64) ? ~0ull : (((1ull << size) - 1ull) << lo)) & remaining;
+        const bool sel = (blk >> lane) & 1ull;
+        // all of the block's lanes aimed at the same light?  then their lines share that point
+        const int li0 = __builtin_amdgcn_readlane(li, first);
+        const bool one_light = __all(!sel || li == li0) && li0 >= 0 && li0 < S.nl;
+        F3 apex = f3(0.0f, 0.0f, 0.0f);
+        if (one_light) apex = f3(S.lights[li0].point);
+        const Packet P = make_packet(o, nld, sel, abn, one_light, apex);
+        if (!P.ok && size > 1) { size >>= 1; continue; }
+        remaining &= ~blk;
+        if (!P.ok) { fallback |= blk; continue; }
+        pk_blocks++; pk_ok += P.ok ? 1 : 0;
+        // lanes outside the block sit this round out
+        const bool done_keep = done;
+        const F3 fo_keep = fo, fd_keep = fd;
+        if (!sel) { done = true; fo = f3(1e18f, 0.0f, 0.0f); fd = f3(0.0f, 0.0f, 0.0f); }
+        if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
+            bool out = __all(done);
+            for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+                const int c = cb + lane;
+                unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+                pk_batches++;
+                while (cm && !out) {
+                    const int j = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    const size_t m = (size_t)(cb + j) * 64 + lane;
+                    const float4 mb = S.smem[m];
+                    const int k = S.sidx[m];
+                    unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
+                    pk_batches++; pk_surv += __popcll(mm);
+                    while (mm) {
+                        const int u = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const float4 br = bcast4(mb, u);
+                        if (!done && !(filt(fo, fd, br) < 0.0f)) {
+                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                            }
                         }
                     }
+                    out = __all(done);
                 }
-                out = __all(done);
             }
         }
-    } else {
-        for (int g = c0; g < c1 && !__all(done); g += kGroup) {
-            const int gend = min(kGroup, c1 - g);
-            unsigned acc = accinit;
-            for (int u = 0; u < gend; u++) acc &= __float_as_uint(filt(fo, fd, S.sbounds[g + u]));
-            if ((int)acc >= 0) {
-                for (int u = 0; u < gend; u++)
-                    if (!done && (abn || !(filt(fo, fd, S.sbounds[g + u]) < 0.0f))) {
-                        if (exact_any(S, S.sorder[g + u], o, ld, nld)) {
-                            done = true;
-                            fo = f3(1e18f, 0.0f, 0.0f);
-                            fd = f3(0.0f, 0.0f, 0.0f);
-                            accinit = 0xFFFFFFFFu;
-                            asm volatile("" : "+v"(accinit));
-                        }
-                    }
+        if (!sel) { done = done_keep; fo = fo_keep; fd = fd_keep; }
+    }
+    // Rays that fit no packet (abnormal ones included) are traced one at a time, TRANSPOSED: the ray is
+    // broadcast and the 64 lanes take 64 different primitives each round, filter and exact test.
+    const int pk_fb = __popcll(fallback);
+    while (fallback) {
+        const int r = __ffsll((long long)fallback) - 1;
+        fallback &= fallback - 1;
+        auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+        const F3 ro = f3(bc(o.x), bc(o.y), bc(o.z)), rl = f3(bc(ld.x), bc(ld.y), bc(ld.z)), rn = f3(bc(nld.x), bc(nld.y), bc(nld.z));
+        const F3 rfo = f3(bc(fo.x), bc(fo.y), bc(fo.z)), rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));
+        const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
+        bool blocked = false;
+        for (int g = c0; g < c1 && !blocked; g += 64) {
+            const int gi = g + lane;
+            bool hit = false;
+            if (gi < c1) {
+                const float4 rec = S.sbounds[gi];
+                if (rabn || !(filt(rfo, rfd, rec) < 0.0f)) hit = exact_any(S, S.sorder[gi], ro, rl, rn);
             }
+            blocked = __any(hit);
         }
+        if (lane == r && blocked) done = true;
     }
     if (S.pstat && lane == 0) {
-        atomicAdd(S.pstat + 4, 1ull); atomicAdd(S.pstat + 5, P.ok ? 1ull : 0ull);
+        atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
         atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv);
     }
     // Order-preserving compaction: the workgroup's survivors keep their order and occupy a run of slots
@@ -1361,7 +1407,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
 {
     __shared__ float4 tile[kTile];
     const int n = *cnt_in;
-    if (n > kThinRays) {
+    if (n > kThinShadow) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;  // block-uniform
         shadow_pass_packet(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, lit_cap, tile);
@@ -1694,7 +1740,8 @@ struct rtx_context {
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
     int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr; int* d_bsum = nullptr;
     unsigned long long* d_pstat = nullptr;
-    int* d_perm = nullptr; int* d_dummy = nullptr;
+    int* d_perm = nullptr; int* d_dummy = nullptr; int* d_braw = nullptr;
+    size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
     int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
     int scnt_stride = 0, nframe_chunks = 0;
@@ -1925,6 +1972,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     }
     {   // shadow-ray queues: the largest generation's hits x lights
         size_t qcap = (size_t)c->L[levels - 1].cap * (size_t)std::max(c->S.nl, 1);
+        c->binG = 256;
+        while ((size_t)std::max(c->S.nl, 1) * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
+        c->nbins = std::max(c->S.nl, 1) * c->binG * c->binG;
+        c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
+        qcap += c->qpad;
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
         for (ShadowQ& q : c->sq) {
             float** fl[] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz};
@@ -1932,14 +1984,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 if ((rc = c->dalloc(f, qcap))) return rc;
             if ((rc = c->dalloc(&q.id, qcap))) return rc;
         }
-        c->binG = 256;
-        while ((size_t)std::max(c->S.nl, 1) * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
-        c->nbins = std::max(c->S.nl, 1) * c->binG * c->binG;
         const size_t maxbins = std::max<size_t>((size_t)c->nbins, (size_t)kRayBins);
         if ((rc = c->dalloc(&c->d_hist, maxbins))) return rc;
         if ((rc = c->dalloc(&c->d_offs, maxbins))) return rc;
         if ((rc = c->dalloc(&c->d_rank, qcap))) return rc;
         if ((rc = c->dalloc(&c->d_bsum, (maxbins + 1023) / 1024))) return rc;
+        if ((rc = c->dalloc(&c->d_braw, (maxbins + 1023) / 1024))) return rc;
         if ((rc = c->dalloc(&c->d_perm, (size_t)c->L[levels - 1].cap))) return rc;
         if ((rc = c->dalloc(&c->d_dummy, (size_t)1))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
@@ -1999,9 +2049,9 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)kRayBins, st));
                 hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_hist, c->d_rank);
                 const int nb = kRayBins / 1024;
-                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, kRayBins, c->d_bsum);
+                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, kRayBins, c->d_bsum, c->d_braw, 1);
                 hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, c->d_dummy);
-                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, kRayBins, c->d_bsum);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, kRayBins, c->d_bsum, c->d_braw, 1, (int*)nullptr);
                 hipLaunchKernelGGL(k_ray_scatter, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_offs, c->d_rank, c->d_perm);
                 perm = c->d_perm;
             }
@@ -2025,12 +2075,12 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_hist, c->d_rank);
                 {
                     const int nb = (c->nbins + 1023) / 1024;
-                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, c->nbins, c->d_bsum);
+                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64);
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, c->nbins, c->d_bsum);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64, c->sq[0].id);
                 }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_offs, c->d_rank, c->sq[0]);
-                unsigned gq = grid_for_isect(live_cap * (size_t)c->S.nl);
+                unsigned gq = grid_for_isect(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
                 const int npass = (int)c->sched.size() - 1;
                 for (int p = 0; p < npass; p++) {
                     if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }

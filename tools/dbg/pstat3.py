@@ -4,8 +4,6 @@ import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
-ctx = rt.Context(sc, rt.Params.make(3840, 2160, 1, flags=rt.host.F_PACKET_STATS))
+ctx = rt.Context(sc, rt.Params.make(3840, 2160, 0, flags=rt.host.F_PACKET_STATS))
 ctx.render(); st = ctx.stats()
-ps = list(st.packet_stats)
-print("abn", ps[1] >> 32, "slot7", ps[7], "rays", list(st.rays_level)[:3], flush=True)
 ctx.close()
