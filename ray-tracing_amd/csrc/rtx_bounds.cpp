@@ -210,6 +210,7 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
     double R2 = rad * rad * (1.0 + 1.0 / 4096.0) + 1e-30;
     if (!(R2 < 1e37)) return r;
     r.neg_r2 = -up(R2);
+    r.pad0 = up(nA * nB * 1.001);  // >= cond(A): the packet test of the shadow kernel scales its cone by it
     return r;
 }
 

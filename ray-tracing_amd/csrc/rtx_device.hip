@@ -333,70 +333,6 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
     }
 }
 
-template <int R>
-__device__ __forceinline__ void closest_body(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
-{
-    F3 o[R], d[R], nd[R], fo[R], fd[R];
-    bool live[R], abn[R];
-    HitAcc h[R];
-    unsigned accinit[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int i = base + r * kBlock + threadIdx.x;
-        live[r] = i < n;
-        int ii = live[r] ? i : 0;
-        o[r] = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
-        d[r] = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
-        nd[r] = normalized(d[r]);
-        abn[r] = ray_abnormal(o[r], d[r], nd[r], S.guard);
-        bool use = live[r] && !abn[r];
-        // lanes that must never pass look at the scene from 1e18 away with a null direction
-        fo[r] = use ? o[r] : f3(1e18f, 0.0f, 0.0f);
-        fd[r] = use ? f3(nd[r].x * kDirScale, nd[r].y * kDirScale, nd[r].z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-        accinit[r] = (live[r] && abn[r]) ? 0u : 0xFFFFFFFFu;  // abnormal lanes always take the exact path
-        asm volatile("" : "+v"(accinit[r]));                  // keep it a plain v_and operand (no v_cndmask)
-        h[r].nearest = kMaxT; h[r].best = -1; h[r].tflag = 0; h[r].txf = kMaxT;
-    }
-    const int nprim = S.ns + S.nt;
-    for (int t0 = 0; t0 < nprim; t0 += kTile) {
-        __syncthreads();
-        int cnt = stage_tile(tile, S.bounds, t0, nprim);
-        __syncthreads();
-        for (int g = 0; g < cnt; g += kGroup) {
-            unsigned acc[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = accinit[r];
-#pragma unroll
-            for (int u = 0; u < kGroup; u++) {
-                float4 b = tile[g + u];
-#pragma unroll
-                for (int r = 0; r < R; r++) acc[r] &= __float_as_uint(filt(fo[r], fd[r], b));
-            }
-            unsigned any = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < R; r++) any &= acc[r];
-            if ((int)any >= 0) {  // some F in this group is not negative for this lane
-                int gend = min(kGroup, cnt - g);
-                for (int u = 0; u < gend; u++) {
-                    float4 b = tile[g + u];
-                    int k = t0 + g + u;
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (live[r] && (abn[r] || !(filt(fo[r], fd[r], b) < 0.0f))) exact_closest(S, k, o[r], d[r], nd[r], h[r]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int i = base + r * kBlock + threadIdx.x;
-        if (live[r]) {
-            L.t[i] = h[r].nearest;
-            L.prim[i] = (h[r].best < 0) ? -1 : (h[r].best | h[r].tflag);
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Packet test.  A wave's 64 rays are bounded by a sphere around their origins (co, rho) and a cone
@@ -1115,90 +1051,27 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
     Q.id[q] = li * L.cap + j;
 }
 
-template <int R>
-__device__ __forceinline__ void shadow_pass_body(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n, const int base,
-                                                 const int c0, const int c1, int* cnt_out, unsigned char* lit, float4* tile)
+// Affine spheres.  The reference maps only the
+// DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against the
+// sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
+__device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, float4 m2, float4 m3)
 {
-    F3 o[R], ld[R], nld[R], fo[R], fd[R];
-    bool live[R], abn[R], done[R];
-    int id[R];
-    unsigned accinit[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int i = base + r * kBlock + threadIdx.x;
-        live[r] = i < n;
-        int ii = live[r] ? i : 0;
-        o[r] = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
-        ld[r] = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
-        id[r] = Qi.id[ii];
-        nld[r] = normalized(ld[r]);  // :575 for untransformed spheres
-        abn[r] = ray_abnormal(o[r], ld[r], nld[r], S.guard);
-        bool use = live[r] && !abn[r];
-        fo[r] = use ? o[r] : f3(1e18f, 0.0f, 0.0f);
-        fd[r] = use ? f3(nld[r].x * kDirScale, nld[r].y * kDirScale, nld[r].z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-        accinit[r] = (live[r] && abn[r]) ? 0u : 0xFFFFFFFFu;
-        asm volatile("" : "+v"(accinit[r]));
-        done[r] = !live[r];
-    }
-    for (int t0 = c0; t0 < c1; t0 += kTile) {
-        bool alldone = true;
-#pragma unroll
-        for (int r = 0; r < R; r++) alldone = alldone && done[r];
-        if (__syncthreads_and(alldone)) break;  // every ray of the workgroup is blocked
-        int cnt = stage_tile(tile, S.sbounds, t0, c1);
-        __syncthreads();
-        if (__all(alldone)) continue;  // this wave is finished; it only keeps the barriers company
-        for (int g = 0; g < cnt; g += kGroup) {
-            unsigned acc[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = accinit[r];
-#pragma unroll
-            for (int u = 0; u < kGroup; u++) {
-                float4 b = tile[g + u];
-#pragma unroll
-                for (int r = 0; r < R; r++) acc[r] &= __float_as_uint(filt(fo[r], fd[r], b));
-            }
-            unsigned any = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < R; r++) any &= acc[r];
-            if ((int)any >= 0) {
-                int gend = min(kGroup, cnt - g);
-                for (int u = 0; u < gend; u++) {
-                    float4 b = tile[g + u];
-                    int k = S.sorder[t0 + g + u];
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (!done[r] && (abn[r] || !(filt(fo[r], fd[r], b) < 0.0f))) {
-                            if (exact_any(S, k, o[r], ld[r], nld[r])) {
-                                done[r] = true;  // blocked: stop passing the filter from here on
-                                fo[r] = f3(1e18f, 0.0f, 0.0f);
-                                fd[r] = f3(0.0f, 0.0f, 0.0f);
-                                accinit[r] = 0xFFFFFFFFu;
-                                asm volatile("" : "+v"(accinit[r]));
-                            }
-                        }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        bool survive = live[r] && !done[r];
-        int slot = wave_alloc(survive, cnt_out);  // ballot-compacted queue of the rays still unblocked
-        if (survive) {
-            Qo.ox[slot] = o[r].x; Qo.oy[slot] = o[r].y; Qo.oz[slot] = o[r].z;
-            Qo.dx[slot] = ld[r].x; Qo.dy[slot] = ld[r].y; Qo.dz[slot] = ld[r].z;
-            Qo.id[slot] = id[r];
-        } else if (live[r]) {
-            lit[id[r]] = 0;
-        }
-    }
+    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
+    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
+    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
+    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
+    float X = o.x - m2.y, Y = o.y - m2.z, Z = o.z - m2.w;
+    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
+    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
+    return __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
 }
 
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
-__device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n, const int base,
-                                                   const int c0, const int c1, int* cnt_out, unsigned char* lit, const int lit_cap, float4* tile)
+__device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
+                                                   unsigned char* lit, const int lit_cap)
 {
+    const int c0 = 0, c1 = S.nsb;
     const int lane = threadIdx.x & 63;
     const int i = base + threadIdx.x;
     const int ii = (i < n) ? i : 0;
@@ -1279,6 +1152,77 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     out = __all(done);
                 }
             }
+            // Affine spheres (raytracing.cpp:571-576: only the DIRECTION is mapped, q = ld*A, the origin stays
+            // in world space).  Packet test, one sphere per lane: with a reference point Lr (the light, or the
+            // packet's origin centre) every origin is Lr - D w + e, D in [Dmin, Dmax], |e| <= rperp, and every
+            // direction is (w + delta) A with |delta| <= chord.  For a unit axis a orthogonal to q_w = w A the
+            // point p of a line nearest the sphere centre c has a.(p - Lr) = -D (a.w) + a.e + s a.(delta A),
+            // |s| |q| = |p - o| <= |c - o|, and the per-ray filter (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)
+            // passes only if |p - c| <= R + tan(alpha) |p - o|, tan^2(alpha) <= 2^-13 + 2^-19.  So a sphere some
+            // ray can pass has, on BOTH axes of an orthonormal pair around q_w,
+            //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
+            //     T = R + rperp + (kappa (chord + 1e-5) + 0.0112)(|c - Lr| + Dmax') + rounding slack,
+            // kappa >= cond(A) from the record.  Everything else is skipped for the whole block.
+            if (!out && S.naff > 0) {
+                const F3 Lr = one_light ? apex : P.co;
+                const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
+                const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
+                const F3 rel = f3(Lr.x - oo.x, Lr.y - oo.y, Lr.z - oo.z);
+                const float D = P.w.x * rel.x + P.w.y * rel.y + P.w.z * rel.z;
+                const F3 e = f3(D * P.w.x - rel.x, D * P.w.y - rel.y, D * P.w.z - rel.z);
+                const float Dmin = wave_min(D), Dmax = wave_max(D);
+                const float Dfar = wave_max(sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
+                const float rperp = wave_max(sqrtf(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
+                const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * sqrtf(P.cosT2))) * 1.0001f + 2e-5f;
+                for (int a0 = 0; a0 < S.naff && !out; a0 += 64) {
+                    const int ai = min(a0 + lane, S.naff - 1);
+                    const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+                    const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+                    bool pass = a0 + lane < S.naff;
+                    {
+                        const F3 w = P.w;
+                        float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
+                        float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
+                        float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
+                        const float qn = sqrtf(qx * qx + qy * qy + qz * qz);
+                        const float R = sqrtf(-m3.x) * 1.00001f;   // +inf for records that always pass, NaN never arises (m3.x <= 0)
+                        const float kappa = m3.z;
+                        if (qn > 1e-18f && qn < 1e18f && R < 1e18f && kappa >= 1.0f && kappa < 1e6f) {
+                            const float inv = 1.0f / qn;
+                            qx *= inv; qy *= inv; qz *= inv;
+                            // orthonormal pair around q (Duff et al.), good to ~1e-6
+                            const float sg = (qz >= 0.0f) ? 1.0f : -1.0f;
+                            const float aa = -1.0f / (sg + qz);
+                            const float bb = qx * qy * aa;
+                            const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
+                            const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
+                            const F3 E = f3(m2.y - Lr.x, m2.z - Lr.y, m2.w - Lr.z);
+                            const float dist = sqrtf(E.x * E.x + E.y * E.y + E.z * E.z);
+                            const float T = (R + rperp + (kappa * chord + 0.0112f) * (dist + Dfar)) * 1.0001f + 1e-5f * (dist + Dfar);
+                            const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
+                            const float t2 = ax2.x * w.x + ax2.y * w.y + ax2.z * w.z, e2 = ax2.x * E.x + ax2.y * E.y + ax2.z * E.z;
+                            const float lo1 = fminf(-Dmin * t1, -Dmax * t1), hi1 = fmaxf(-Dmin * t1, -Dmax * t1);
+                            const float lo2 = fminf(-Dmin * t2, -Dmax * t2), hi2 = fmaxf(-Dmin * t2, -Dmax * t2);
+                            if (e1 < lo1 - T || e1 > hi1 + T || e2 < lo2 - T || e2 > hi2 + T) pass = false;
+                        }
+                    }
+                    unsigned long long am = __ballot(pass);
+                    pk_batches++; pk_surv += __popcll(am);
+                    while (am) {
+                        const int u = __ffsll((long long)am) - 1;
+                        am &= am - 1;
+                        const float4 b0 = bcast4(m0, u), b1 = bcast4(m1, u), b2 = bcast4(m2, u), b3 = bcast4(m3, u);
+                        if (!done && !(filt_affine(o, ld, b0, b1, b2, b3) < 0.0f)) {
+                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                    out = __all(done);
+                }
+            }
         }
         if (!sel) { done = done_keep; fo = fo_keep; fd = fd_keep; }
     }
@@ -1302,168 +1246,31 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             }
             blocked = __any(hit);
         }
+        for (int a0 = 0; a0 < S.naff && !blocked; a0 += 64) {
+            const int ai = a0 + lane;
+            bool hit = false;
+            if (ai < S.naff) {
+                const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+                const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+                if (rabn || !(filt_affine(ro, rl, m0, m1, m2, m3) < 0.0f)) hit = exact_any(S, __float_as_int(m3.y), ro, rl, rn);
+            }
+            blocked = __any(hit);
+        }
         if (lane == r && blocked) done = true;
     }
     if (S.pstat && lane == 0) {
         atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
         atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv);
     }
-    // Order-preserving compaction: the workgroup's survivors keep their order and occupy a run of slots
-    // rounded up to whole waves (padding slots carry id = -1), so the next pass's waves are made of rays
-    // that were neighbours in light space -- the packets stay tight from pass to pass.
-    const bool survive = live && !done;
     if (live && done) lit[id] = 0;
-    const unsigned long long sm = __ballot(survive);
-    const int lp = __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0));
-    __syncthreads();  // the tile is no longer read
-    int* sh = reinterpret_cast<int*>(tile);
-    const int w = threadIdx.x >> 6;
-    if (lane == 0) sh[w] = __popcll(sm);
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int k = 0; k < kBlock / 64; k++) { if (k < w) woff += sh[k]; tot += sh[k]; }
-    const int padded = (tot + 63) & ~63;
-    if (threadIdx.x == 0) sh[8] = padded ? atomicAdd(cnt_out, padded) : 0;
-    __syncthreads();
-    const int obase = sh[8];
-    if (survive) {
-        const int slot = obase + woff + lp;
-        Qo.ox[slot] = o.x; Qo.oy[slot] = o.y; Qo.oz[slot] = o.z;
-        Qo.dx[slot] = ld.x; Qo.dy[slot] = ld.y; Qo.dz[slot] = ld.z;
-        Qo.id[slot] = id;
-    }
-    for (int q = tot + (int)threadIdx.x; q < padded; q += kBlock) Qo.id[obase + q] = -1;
 }
 
-// Thin-generation form of a shadow pass: 64 rays per workgroup, the pass's chunk split over the
-// four waves; a ray is blocked if any wave found a blocker (any-hit: plain OR).
-__device__ __forceinline__ void shadow_pass_thin(const SceneDev& S, const ShadowQ& Qi, const ShadowQ& Qo, const int n,
-                                                 const int c0, const int c1, int* cnt_out, unsigned char* lit, float4* tile)
+__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
 {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 64 + lane;
-    const int ii = (i < n) ? i : 0;
-    const int id = Qi.id[ii];
-    const bool live = (i < n) && id >= 0;
-    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
-    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
-    F3 nld = normalized(ld);
-    const bool abn = ray_abnormal(o, ld, nld, S.guard);
-    const bool use = live && !abn;
-    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
-    F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
-    asm volatile("" : "+v"(accinit));
-    bool done = !live;
-    const int SL = (((c1 - c0) + kGroup - 1) / kGroup + 3) / 4 * kGroup;
-    const int p0 = min(c0 + w * SL, c1), p1 = min(p0 + SL, c1);
-    const int T = (SL + kThinTile - 1) / kThinTile;
-    float4* mt = tile + w * kThinTile;
-    for (int tt = 0; tt < T; tt++) {
-        __syncthreads();
-        const int t0 = p0 + tt * kThinTile;
-        const int cnt = stage_thin(mt, S.sbounds, t0, p1, lane);
-        __syncthreads();
-        if (__all(done)) continue;
-        for (int g = 0; g < cnt; g += kGroup) {
-            unsigned acc = accinit;
-#pragma unroll
-            for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, mt[g + u]));
-            if ((int)acc >= 0) {
-                int gend = min(kGroup, cnt - g);
-                for (int u = 0; u < gend; u++)
-                    if (!done && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) {
-                        if (exact_any(S, S.sorder[t0 + g + u], o, ld, nld)) {
-                            done = true;
-                            fo = f3(1e18f, 0.0f, 0.0f);
-                            fd = f3(0.0f, 0.0f, 0.0f);
-                            accinit = 0xFFFFFFFFu;
-                            asm volatile("" : "+v"(accinit));
-                        }
-                    }
-            }
-        }
-    }
-    __syncthreads();
-    int* blocked = reinterpret_cast<int*>(tile);
-    blocked[threadIdx.x] = (live && done) ? 1 : 0;
-    __syncthreads();
-    if (w == 0) {
-        bool b = (blocked[lane] | blocked[64 + lane] | blocked[128 + lane] | blocked[192 + lane]) != 0;
-        bool survive = live && !b;
-        int slot = wave_alloc(survive, cnt_out);
-        if (survive) {
-            Qo.ox[slot] = o.x; Qo.oy[slot] = o.y; Qo.oz[slot] = o.z;
-            Qo.dx[slot] = ld.x; Qo.dy[slot] = ld.y; Qo.dz[slot] = ld.z;
-            Qo.id[slot] = id;
-        } else if (live) {
-            lit[id] = 0;
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, ShadowQ Qo, const int* cnt_in, int* cnt_out,
-                                                        int c0, int c1, unsigned char* lit, int lit_cap)
-{
-    __shared__ float4 tile[kTile];
-    const int n = *cnt_in;
-    if (n > kThinShadow) {
-        const int base = blockIdx.x * kBlock;
-        if (base >= n) return;  // block-uniform
-        shadow_pass_packet(S, Qi, Qo, n, base, c0, c1, cnt_out, lit, lit_cap, tile);
-    } else {
-        if (blockIdx.x * 64 >= n) return;
-        shadow_pass_thin(S, Qi, Qo, n, c0, c1, cnt_out, lit, tile);
-    }
-}
-
-// Affine spheres against the rays that survived every other primitive.  The reference maps only the
-// DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against the
-// sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
-__device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, float4 m2, float4 m3)
-{
-    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
-    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
-    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
-    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
-    float X = o.x - m2.y, Y = o.y - m2.z, Z = o.z - m2.w;
-    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
-    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
-    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
-    return __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
-}
-
-__global__ __launch_bounds__(kBlock) void k_shadow_aff(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit)
-{
-    __shared__ float4 tile[kTile];
     const int n = *cnt_in;
     const int base = blockIdx.x * kBlock;
     if (base >= n) return;  // block-uniform
-    const int i = base + threadIdx.x;
-    const int ii = (i < n) ? i : 0;
-    const int id = Qi.id[ii];
-    const bool live = (i < n) && id >= 0;
-    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
-    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
-    F3 nld = normalized(ld);
-    const bool abn = ray_abnormal(o, ld, nld, S.guard);
-    bool done = !live;
-    constexpr int kAffTile = kTile / 4;
-    for (int a0 = 0; a0 < S.naff; a0 += kAffTile) {
-        if (__syncthreads_and(done)) break;
-        int cnt = min(kAffTile, S.naff - a0);
-        for (int j = threadIdx.x; j < cnt * 4; j += kBlock) tile[j] = S.aff_shadow[(size_t)a0 * 4 + j];
-        __syncthreads();
-        if (__all(done)) continue;
-        for (int u = 0; u < cnt; u++) {
-            float4 m0 = tile[4 * u], m1 = tile[4 * u + 1], m2 = tile[4 * u + 2], m3 = tile[4 * u + 3];
-            float F = filt_affine(o, ld, m0, m1, m2, m3);
-            if (!done && (abn || !(F < 0.0f))) {
-                if (exact_any(S, __float_as_int(m3.y), o, ld, nld)) done = true;
-            }
-        }
-    }
-    if (live && done) lit[id] = 0;
+    shadow_pass_packet(S, Qi, n, base, lit, lit_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1741,6 +1548,14 @@ struct rtx_context {
     int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr; int* d_bsum = nullptr;
     unsigned long long* d_pstat = nullptr;
     int* d_perm = nullptr; int* d_dummy = nullptr; int* d_braw = nullptr;
+    // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
+    // k_setup(k): the shadow chain runs on a second stream (fork after every set-up, one join before the
+    // unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
+    // The ray binning of the closest-hit pass has scan buffers of its own for that reason.
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_fork;
+    hipEvent_t ev_join = nullptr;
+    int* r_hist = nullptr; int* r_offs = nullptr; int* r_rank = nullptr; int* r_bsum = nullptr; int* r_braw = nullptr;
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
     int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
@@ -1984,7 +1799,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 if ((rc = c->dalloc(f, qcap))) return rc;
             if ((rc = c->dalloc(&q.id, qcap))) return rc;
         }
-        const size_t maxbins = std::max<size_t>((size_t)c->nbins, (size_t)kRayBins);
+        const size_t maxbins = (size_t)c->nbins;
+        if ((rc = c->dalloc(&c->r_hist, (size_t)kRayBins))) return rc;
+        if ((rc = c->dalloc(&c->r_offs, (size_t)kRayBins))) return rc;
+        if ((rc = c->dalloc(&c->r_rank, (size_t)c->L[levels - 1].cap))) return rc;
+        if ((rc = c->dalloc(&c->r_bsum, (size_t)kRayBins / 1024))) return rc;
+        if ((rc = c->dalloc(&c->r_braw, (size_t)kRayBins / 1024))) return rc;
         if ((rc = c->dalloc(&c->d_hist, maxbins))) return rc;
         if ((rc = c->dalloc(&c->d_offs, maxbins))) return rc;
         if ((rc = c->dalloc(&c->d_rank, qcap))) return rc;
@@ -1998,6 +1818,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     }
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    c->ev_fork.resize(levels);
+    for (auto& e : c->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (params->flags & RTX_F_TIME_KERNELS) {
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->kev.resize((size_t)nchunks * levels * 2 * (1 + c->sched.size()));
@@ -2036,6 +1860,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
         L0.val = c->d_fimg + (size_t)ti0 * W * 3;
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
         size_t live_cap = npix;  // upper bound on live rays at this level
+        bool forked = false;
         std::vector<size_t> bound(levels);
         for (int k = 0; k < levels; k++) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
@@ -2046,13 +1871,13 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             const int* perm = nullptr;
             if (k > 0 && !count && !exact_only) {
                 // bin the secondary rays by (origin cell, direction cell) so that waves are coherent packets
-                HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)kRayBins, st));
-                hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_hist, c->d_rank);
+                HIPCHK(hipMemsetAsync(c->r_hist, 0, sizeof(int) * (size_t)kRayBins, st));
+                hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->r_hist, c->r_rank);
                 const int nb = kRayBins / 1024;
-                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, kRayBins, c->d_bsum, c->d_braw, 1);
-                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, c->d_dummy);
-                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, kRayBins, c->d_bsum, c->d_braw, 1, (int*)nullptr);
-                hipLaunchKernelGGL(k_ray_scatter, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_offs, c->d_rank, c->d_perm);
+                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->r_hist, c->r_offs, kRayBins, c->r_bsum, c->r_braw, 1);
+                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->r_bsum, nb, c->d_dummy);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->r_offs, kRayBins, c->r_bsum, c->r_braw, 1, (int*)nullptr);
+                hipLaunchKernelGGL(k_ray_scatter, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->r_offs, c->r_rank, c->d_perm);
                 perm = c->d_perm;
             }
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
@@ -2069,29 +1894,31 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 else hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             } else if (c->S.nl > 0) {
-                // materialise the shadow rays, then chunked any-hit passes with compaction in between
+                // materialise the shadow rays, then chunked any-hit passes with compaction in between -- on the side stream
+                hipStream_t ss = c->side;
+                HIPCHK(hipEventRecord(c->ev_fork[k], st));
+                HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
+                forked = true;
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k) * c->scnt_stride;
-                HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)c->nbins, st));
-                hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_hist, c->d_rank);
+                HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)c->nbins, ss));
+                hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, c->d_hist, c->d_rank);
                 {
                     const int nb = (c->nbins + 1023) / 1024;
-                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->d_hist, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64);
-                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->d_bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64, c->sq[0].id);
+                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, c->d_hist, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64);
+                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, c->d_bsum, nb, sc + 0);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64, c->sq[0].id);
                 }
-                hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->binG, c->d_offs, c->d_rank, c->sq[0]);
-                unsigned gq = grid_for_isect(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
-                const int npass = (int)c->sched.size() - 1;
-                for (int p = 0; p < npass; p++) {
-                    if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
-                    hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, st, c->S, c->sq[p & 1], c->sq[(p + 1) & 1], sc + p, sc + p + 1,
-                                       c->sched[p], c->sched[p + 1], Lk.lit, Lk.cap);
-                    if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
-                }
-                if (c->S.naff > 0)
-                    hipLaunchKernelGGL(k_shadow_aff, dim3(gq), dim3(kBlock), 0, st, c->S, c->sq[npass & 1], sc + npass, Lk.lit);
+                hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, c->d_offs, c->d_rank, c->sq[0]);
+                unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
+                if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
+                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, c->sq[0], sc + 0, Lk.lit, Lk.cap);
+                if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
             }
             if (c->fanout >= 2) live_cap *= 2;
+        }
+        if (forked) {
+            HIPCHK(hipEventRecord(c->ev_join, c->side));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
         }
         for (int k = levels - 1; k >= 0; k--) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
@@ -2146,6 +1973,9 @@ void rtx_context_destroy(rtx_context* c)
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
+        for (auto e : c->ev_fork) if (e) (void)hipEventDestroy(e);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        if (c->side) (void)hipStreamDestroy(c->side);
     }
     delete c;
 }
@@ -2218,25 +2048,6 @@ int rtx_context_stats(rtx_context* c, rtx_stats* s)
     for (int k = 0; k < 8; k++) s->packet_stats[k] = tk[k];
     HIPCHK(hipMemcpy(tk, c->d_tests, sizeof tk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = tk[k]; s->tests_shadow_kind[k] = tk[4 + k]; }
-    if (!(c->params.flags & (RTX_F_COUNT_TESTS | RTX_F_EXACT_ONLY)) && c->S.nl > 0) {
-        // chunked shadow passes: every ray alive at the start of a pass is tested against the whole chunk
-        std::vector<int> sc((size_t)std::max(c->nframe_chunks, 1) * c->levels * c->scnt_stride);
-        HIPCHK(hipMemcpy(sc.data(), c->d_scnt, sc.size() * sizeof(int), hipMemcpyDeviceToHost));
-        const int npass = (int)c->sched.size() - 1;
-        std::vector<uint64_t> nsph(npass, 0), ntri(npass, 0);
-        for (int p = 0; p < npass; p++)
-            for (int i = c->sched[p]; i < c->sched[p + 1]; i++) (c->sb_kind[i] == 0 ? nsph[p] : ntri[p])++;
-        for (int k = 0; k < 4; k++) s->tests_shadow_kind[k] = 0;
-        for (int ch = 0; ch < c->nframe_chunks; ch++)
-            for (int k = 0; k < c->levels; k++) {
-                const int* q = sc.data() + ((size_t)ch * c->levels + k) * c->scnt_stride;
-                for (int p = 0; p < npass; p++) {
-                    s->tests_shadow_kind[0] += (uint64_t)q[p] * nsph[p];
-                    s->tests_shadow_kind[2] += (uint64_t)q[p] * ntri[p];
-                }
-                s->tests_shadow_kind[1] += (uint64_t)q[npass] * (uint64_t)c->S.naff;
-            }
-    }
     for (size_t e = 0; e < c->kev_kind.size(); e++) {
         float m = 0;
         HIPCHK(hipEventElapsedTime(&m, c->kev[2 * e], c->kev[2 * e + 1]));
