@@ -1543,18 +1543,23 @@ struct rtx_context {
     int* d_cnt = nullptr;                   // [2*levels]: rays per level, then nodes per level
     unsigned long long* d_totals = nullptr; // [2*levels]
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
-    ShadowQ sq[2] = {};                     // ping-pong shadow-ray queues
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
-    int* d_hist = nullptr; int* d_offs = nullptr; int* d_rank = nullptr; int* d_bsum = nullptr;
     unsigned long long* d_pstat = nullptr;
-    int* d_perm = nullptr; int* d_dummy = nullptr; int* d_braw = nullptr;
+    int* d_perm = nullptr; int* d_dummy = nullptr;
     // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
-    // k_setup(k): the shadow chain runs on a second stream (fork after every set-up, one join before the
-    // unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
-    // The ray binning of the closest-hit pass has scan buffers of its own for that reason.
-    hipStream_t side = nullptr;
+    // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream k % kSide with
+    // that stream's own queue and scan buffers (fork after every set-up, one join per side stream before
+    // the unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
+    // The ray binning of the closest-hit pass has scan buffers of its own for the same reason.
+    static constexpr int kSide = 3;
+    struct ShadowLane {
+        hipStream_t stream = nullptr;
+        hipEvent_t join = nullptr;
+        ShadowQ q = {};
+        int* hist = nullptr; int* offs = nullptr; int* rank = nullptr; int* bsum = nullptr; int* braw = nullptr;
+        bool used = false;
+    } side[kSide];
     std::vector<hipEvent_t> ev_fork;
-    hipEvent_t ev_join = nullptr;
     int* r_hist = nullptr; int* r_offs = nullptr; int* r_rank = nullptr; int* r_bsum = nullptr; int* r_braw = nullptr;
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
@@ -1758,8 +1763,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     double mult = 0, m = 1;
     for (int k = 0; k < levels; k++) { mult += m; m *= (c->fanout >= 2 ? 2.0 : 1.0); }
     uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
-    // per level-0 ray: every level's slots, plus the two shadow-ray queues sized for the largest level
-    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * 2.0 * 28.0 * (double)c->S.nl);
+    // per level-0 ray: every level's slots, plus the side streams' shadow-ray queues (28 B a ray + 4 B rank) sized for the largest level
+    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * (double)std::min(levels, (int)rtx_context::kSide) * 32.0 * (double)c->S.nl);
     int64_t rows = (int64_t)((double)budget / per_row);
     if (rows < 1) rows = 1;
     if (rows > ntrace) rows = ntrace;
@@ -1793,23 +1798,25 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
         qcap += c->qpad;
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
-        for (ShadowQ& q : c->sq) {
-            float** fl[] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz};
+        const size_t maxbins = (size_t)c->nbins;
+        const int nside = std::min(levels, (int)rtx_context::kSide);
+        for (int i = 0; i < nside; i++) {
+            rtx_context::ShadowLane& sl = c->side[i];
+            float** fl[] = {&sl.q.ox, &sl.q.oy, &sl.q.oz, &sl.q.dx, &sl.q.dy, &sl.q.dz};
             for (float** f : fl)
                 if ((rc = c->dalloc(f, qcap))) return rc;
-            if ((rc = c->dalloc(&q.id, qcap))) return rc;
+            if ((rc = c->dalloc(&sl.q.id, qcap))) return rc;
+            if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
+            if ((rc = c->dalloc(&sl.offs, maxbins))) return rc;
+            if ((rc = c->dalloc(&sl.rank, qcap))) return rc;
+            if ((rc = c->dalloc(&sl.bsum, (maxbins + 1023) / 1024))) return rc;
+            if ((rc = c->dalloc(&sl.braw, (maxbins + 1023) / 1024))) return rc;
         }
-        const size_t maxbins = (size_t)c->nbins;
         if ((rc = c->dalloc(&c->r_hist, (size_t)kRayBins))) return rc;
         if ((rc = c->dalloc(&c->r_offs, (size_t)kRayBins))) return rc;
         if ((rc = c->dalloc(&c->r_rank, (size_t)c->L[levels - 1].cap))) return rc;
         if ((rc = c->dalloc(&c->r_bsum, (size_t)kRayBins / 1024))) return rc;
         if ((rc = c->dalloc(&c->r_braw, (size_t)kRayBins / 1024))) return rc;
-        if ((rc = c->dalloc(&c->d_hist, maxbins))) return rc;
-        if ((rc = c->dalloc(&c->d_offs, maxbins))) return rc;
-        if ((rc = c->dalloc(&c->d_rank, qcap))) return rc;
-        if ((rc = c->dalloc(&c->d_bsum, (maxbins + 1023) / 1024))) return rc;
-        if ((rc = c->dalloc(&c->d_braw, (maxbins + 1023) / 1024))) return rc;
         if ((rc = c->dalloc(&c->d_perm, (size_t)c->L[levels - 1].cap))) return rc;
         if ((rc = c->dalloc(&c->d_dummy, (size_t)1))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
@@ -1818,10 +1825,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     }
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int i = 0; i < std::min(levels, (int)rtx_context::kSide); i++) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side[i].stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->side[i].join, hipEventDisableTiming));
+    }
     c->ev_fork.resize(levels);
     for (auto& e : c->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (params->flags & RTX_F_TIME_KERNELS) {
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->kev.resize((size_t)nchunks * levels * 2 * (1 + c->sched.size()));
@@ -1860,7 +1869,6 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
         L0.val = c->d_fimg + (size_t)ti0 * W * 3;
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
         size_t live_cap = npix;  // upper bound on live rays at this level
-        bool forked = false;
         std::vector<size_t> bound(levels);
         for (int k = 0; k < levels; k++) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
@@ -1895,31 +1903,34 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             } else if (c->S.nl > 0) {
                 // materialise the shadow rays, then chunked any-hit passes with compaction in between -- on the side stream
-                hipStream_t ss = c->side;
+                rtx_context::ShadowLane& sl = c->side[k % rtx_context::kSide];
+                hipStream_t ss = sl.stream;
                 HIPCHK(hipEventRecord(c->ev_fork[k], st));
                 HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
-                forked = true;
+                sl.used = true;
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k) * c->scnt_stride;
-                HIPCHK(hipMemsetAsync(c->d_hist, 0, sizeof(int) * (size_t)c->nbins, ss));
-                hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, c->d_hist, c->d_rank);
+                HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
+                hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
                 {
                     const int nb = (c->nbins + 1023) / 1024;
-                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, c->d_hist, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64);
-                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, c->d_bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, c->d_offs, c->nbins, c->d_bsum, c->d_braw, 64, c->sq[0].id);
+                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
+                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.id);
                 }
-                hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, c->d_offs, c->d_rank, c->sq[0]);
+                hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
-                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, c->sq[0], sc + 0, Lk.lit, Lk.cap);
+                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
             }
             if (c->fanout >= 2) live_cap *= 2;
         }
-        if (forked) {
-            HIPCHK(hipEventRecord(c->ev_join, c->side));
-            HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
-        }
+        for (rtx_context::ShadowLane& sl : c->side)
+            if (sl.used) {
+                HIPCHK(hipEventRecord(sl.join, sl.stream));
+                HIPCHK(hipStreamWaitEvent(st, sl.join, 0));
+                sl.used = false;
+            }
         for (int k = levels - 1; k >= 0; k--) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
             LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
@@ -1974,8 +1985,10 @@ void rtx_context_destroy(rtx_context* c)
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
         for (auto e : c->ev_fork) if (e) (void)hipEventDestroy(e);
-        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-        if (c->side) (void)hipStreamDestroy(c->side);
+        for (rtx_context::ShadowLane& sl : c->side) {
+            if (sl.join) (void)hipEventDestroy(sl.join);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        }
     }
     delete c;
 }
