@@ -594,10 +594,10 @@ __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, 
     }
 }
 
-__device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
+__device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int q, float4* tile, const int* perm,
+                                              const int sub, const int nsub)
 {
     const int lane = threadIdx.x & 63;
-    const int q = base + threadIdx.x;
     const bool live = q < n;
     const int i = live ? (perm ? perm[q] : q) : 0;
     F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
@@ -640,6 +640,7 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
             }
             if (abn) cmask = (ce == 32) ? ~0u : ((1u << ce) - 1u);
             if (!live) cmask = 0u;
+            if (phase == 1 && nsub == 4) cmask &= 0x11111111u << sub;  // split generation: this lane's quarter of the clusters
             // (2) sub-cluster spheres of the lane's own passing clusters -> queue of (cluster slot, group mask)
             int nq = 0;
             while (__any(cmask != 0u)) {
@@ -689,6 +690,19 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
         }
         flush();  // phase 0: every affine-sphere hit is known before the first plain sphere is tested
     }
+    if (nsub == 4) {
+        // the four lanes of a ray hold the same affine list (phase 0 is not split) with their own kills, and
+        // their own nearest hit: an entry lives if no lane removed it, the lexicographic minimum wins
+#pragma unroll
+        for (int m = 1; m <= 2; m <<= 1) {
+            const float t2 = __shfl_xor(h.nearest, m);
+            const int b2 = __shfl_xor(h.best, m);
+            if (t2 < h.nearest || (t2 == h.nearest && b2 < h.best)) { h.nearest = t2; h.best = b2; }
+#pragma unroll
+            for (int e = 0; e < kAffList; e++) h.ak[e] = min(h.ak[e], __shfl_xor(h.ak[e], m));
+            h.overflow = h.overflow || (__shfl_xor((int)h.overflow, m) != 0);
+        }
+    }
     bool alive = false;
 #pragma unroll
     for (int e = 0; e < kAffList; e++) alive = alive || h.ak[e] >= 0;
@@ -715,7 +729,7 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
             atomicAdd(S.pstat + 2, (unsigned long long)flushes); atomicAdd(S.pstat + 3, (unsigned long long)tot);
         }
     }
-    if (live) {
+    if (live && sub == 0) {
         L.t[i] = nearest;
         L.prim[i] = (best < 0) ? -1 : (best | tflag);
     }
@@ -813,13 +827,24 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
     }
 }
 
+// Generations of at most kSplitClosest rays put FOUR lanes on every ray (64 rays per workgroup): the lanes
+// share the affine-sphere clusters and take a quarter of the others each, and merge at the end.  A thin
+// generation has fewer waves than the chip has SIMDs; its run time is one wave's serial walk, now a
+// third as long.
+constexpr int kSplitClosest = 1 << 17;
+
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
     __shared__ float4 tile[kLaneLds * (kBlock / 64) / 16];  // the four waves' candidate lists and cluster queues (40 KiB)
     const int n = *nrays;
-    const int base = blockIdx.x * kBlock;
-    if (base >= n) return;  // block-uniform
-    closest_lanes(S, L, n, base, tile, n > kThinRays ? perm : nullptr);
+    const int* pm = n > kThinRays ? perm : nullptr;
+    if (n <= kSplitClosest) {
+        if (blockIdx.x * 64 >= n) return;  // block-uniform
+        closest_lanes(S, L, n, blockIdx.x * 64 + (threadIdx.x >> 2), tile, pm, threadIdx.x & 3, 4);
+    } else {
+        if (blockIdx.x * kBlock >= n) return;
+        closest_lanes(S, L, n, blockIdx.x * kBlock + threadIdx.x, tile, pm, 0, 1);
+    }
 }
 
 // exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
@@ -1069,7 +1094,7 @@ __device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, f
 
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
-                                                   unsigned char* lit, const int lit_cap)
+                                                   unsigned char* lit, const int lit_cap, const int part, const int parts)
 {
     const int c0 = 0, c1 = S.nsb;
     const int lane = threadIdx.x & 63;
@@ -1127,7 +1152,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             bool out = __all(done);
             for (int cb = 0; cb < S.sncl && !out; cb += 64) {
                 const int c = cb + lane;
-                unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+                unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
                 pk_batches++;
                 while (cm && !out) {
                     const int j = __ffsll((long long)cm) - 1;
@@ -1174,7 +1199,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 const float Dfar = wave_max(sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
                 const float rperp = wave_max(sqrtf(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
                 const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * sqrtf(P.cosT2))) * 1.0001f + 2e-5f;
-                for (int a0 = 0; a0 < S.naff && !out; a0 += 64) {
+                for (int a0 = part * 64; a0 < S.naff && !out; a0 += 64 * parts) {
                     const int ai = min(a0 + lane, S.naff - 1);
                     const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
                     const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
@@ -1237,7 +1262,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         const F3 rfo = f3(bc(fo.x), bc(fo.y), bc(fo.z)), rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));
         const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
         bool blocked = false;
-        for (int g = c0; g < c1 && !blocked; g += 64) {
+        for (int g = c0 + part * 64; g < c1 && !blocked; g += 64 * parts) {
             const int gi = g + lane;
             bool hit = false;
             if (gi < c1) {
@@ -1246,7 +1271,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             }
             blocked = __any(hit);
         }
-        for (int a0 = 0; a0 < S.naff && !blocked; a0 += 64) {
+        for (int a0 = part * 64; a0 < S.naff && !blocked; a0 += 64 * parts) {
             const int ai = a0 + lane;
             bool hit = false;
             if (ai < S.naff) {
@@ -1265,12 +1290,20 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     if (live && done) lit[id] = 0;
 }
 
+// A thin generation (<= kSplitRays shadow rays) is traced by kSplit workgroups per 256 rays, each taking every
+// kSplit-th cluster and affine batch: a ray is blocked if ANY part finds a blocker (each just clears lit[id]),
+// and the serial walk per wave -- what bounds the run time when there are fewer waves than SIMDs can hold --
+// is kSplit times shorter.
+constexpr int kSplit = 4;
+constexpr int kSplitRays = 1 << 20;
+
 __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
 {
     const int n = *cnt_in;
-    const int base = blockIdx.x * kBlock;
+    const int parts = (n <= kSplitRays) ? kSplit : 1;
+    const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
-    shadow_pass_packet(S, Qi, n, base, lit, lit_cap);
+    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1891,7 +1924,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
@@ -1919,6 +1952,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
+                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)kSplitRays)) * kSplit));
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
                 hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
