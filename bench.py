@@ -11,12 +11,12 @@ gather (torch.distributed, backend nccl).  The frame is FIXED as N grows (strong
 value = rays actually traced (primary + reflection/refraction + shadow) per second, whole job.
 
 The JSON line also carries
-  roofline     for the dominant kernel (the shadow any-hit or the closest-hit kernel, whichever
-               took longer): algorithmic FLOPs of the ray x primitive tests it executed
-               (20 / 65 / 76 / 13 FLOP per sphere / affine sphere / triangle /
-               early-exit triangle test, counted by the kernels' counting variants in a separate
-               untimed frame) / its average launch time, measured with HIP events on the launch
-               stream during the timed steps.  The bound is FP32 VALU, not HBM or MFMA.
+  roofline     for the dominant kernel (k_shadow_pass, k_closest_lanes or k_closest_f, whichever took
+               longest): ALGORITHMIC FLOPs of the ray x primitive tests the reference's loops run for
+               the rays that kernel traces (20 / 65 / 76 / 13 FLOP per sphere / affine
+               sphere / triangle / early-exit triangle test, counted by the exact counting kernels in
+               a separate untimed frame) / its launch time, measured with HIP events on the kernel's
+               own stream during the timed steps.  The bound is FP32 VALU, not HBM or MFMA.
   cpu_baseline the reference renderer itself (oracle/_ref/rt_ref, compiled from the reference's
                source in the build container) or, if that binary is absent, this repo's scalar
                C port (oracle/), timed on ONE host core on a small image of the same scene.
@@ -179,28 +179,34 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's share of the frame) ----
     if rank == 0:
-        dom = "shadow" if st.ms_shadow >= st.ms_closest else "closest"
-        ms_dom = st.ms_shadow if dom == "shadow" else st.ms_closest
-        n_dom = st.launches_shadow if dom == "shadow" else st.launches_closest
-        roof = {"bound": "valu-fp32", "kernel": "k_shadow_pass" if dom == "shadow" else "k_closest_f", "achieved": None,
+        kern = {"k_shadow_pass": (st.ms_shadow, st.launches_shadow),
+                "k_closest_lanes": (st.ms_closest_lanes, st.launches_closest_lanes),
+                "k_closest_f": (st.ms_closest, st.launches_closest)}
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms_dom, n_dom = kern[dom]
+        roof = {"bound": "valu-fp32", "kernel": dom, "achieved": None,
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "peak_no_fma": PEAK_FP32_NOFMA_TFLOPS, "frac_no_fma": None,
                 "launches_per_frame": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
-                "ms_closest_per_frame": st.ms_closest, "ms_shadow_per_frame": st.ms_shadow, "ms_frame": st.ms_total}
+                "ms_per_frame_by_kernel": {k: v[0] for k, v in kern.items()}, "ms_frame": st.ms_total,
+                "note": "achieved = the REFERENCE algorithm's test FLOPs for the rays this kernel traces (every primitive in file "
+                        "order, shadow rays leaving at their first blocker; counted by the exact kernels in an untimed frame) / "
+                        "this kernel's summed launch time (HIP events on its own stream; launches of different streams overlap, "
+                        "so the per-kernel times add up to more than ms_frame).  The kernel reaches the same answers "
+                        "through a cluster hierarchy and executes a small part of those tests, hence frac > 1: see DESIGN.md 4.3 "
+                        "for the executed-instruction counters."}
         if not args.no_count:
             cctx = make_ctx(rt.host.F_COUNT_TESTS)
             cctx.render(stream, None)
             cst = cctx.stats()
-            if dom == "shadow":
-                # tests the chunked passes evaluated (timed build); the share of triangle tests that leave
-                # early (13 instead of 76 FLOP) is taken from the exact counting kernels
-                kinds = [float(x) for x in st.tests_shadow_kind]
-                full, early = float(cst.tests_shadow_kind[2]), float(cst.tests_shadow_kind[3])
-                fe = early / max(full + early, 1.0)
-                kinds = [kinds[0], kinds[1], kinds[2] * (1.0 - fe), kinds[2] * fe]
-                roof["tests_file_order_early_exit"] = [float(x) for x in cst.tests_shadow_kind]
+            if dom == "k_shadow_pass":
+                kinds = [float(x) for x in cst.tests_shadow_kind]
             else:
-                kinds = [float(x) for x in cst.tests_closest_kind]
+                # the counting kernel sums over generations; closest-hit tests every primitive for every ray, so a
+                # generation's share is its share of the rays
+                tot = float(st.rays_primary + st.rays_secondary)
+                share = float(st.rays_primary if dom == "k_closest_f" else st.rays_secondary) / max(tot, 1.0)
+                kinds = [float(x) * share for x in cst.tests_closest_kind]
             flops = sum(float(kinds[k]) * FLOP_PER_TEST[k] for k in range(4))
             ach = flops / (ms_dom * 1e-3) / 1e12
             roof.update(achieved=ach, frac=ach / PEAK_FP32_TFLOPS, frac_no_fma=ach / PEAK_FP32_NOFMA_TFLOPS,

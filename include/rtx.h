@@ -116,25 +116,29 @@ typedef struct rtx_stats {
     uint64_t rays_level[RTX_MAX_LEVELS]; /* rays per generation */
     uint64_t tests_closest;     /* ray x primitive tests executed by closest-hit (rays * nprims) */
     uint64_t tests_shadow_max;  /* upper bound for shadow rays (no early exit): rays * nprims */
-    /* Tests executed by kind {sphere, affine sphere, triangle full path, triangle leaving at vd == 0
-     * or t < 0}.  With RTX_F_COUNT_TESTS: counted by the exact kernels (shadow rays: per-ray early exit
-     * in file order).  Otherwise tests_shadow_kind reports what the chunked shadow passes evaluated
-     * (rays alive at the start of a pass x primitives of the pass; triangles all under [2]) and
-     * tests_closest_kind stays 0. */
+    /* RTX_F_COUNT_TESTS only (0 otherwise): the reference algorithm's ray x primitive tests by kind
+     * {sphere, affine sphere, triangle full path, triangle leaving at vd == 0 or t < 0}, counted by the
+     * exact kernels that walk every primitive in file order as raytracing.cpp does (shadow rays: per-ray
+     * early exit).  The ALGORITHMIC work of the frame; the production kernels cull most of it. */
     uint64_t tests_closest_kind[4];
     uint64_t tests_shadow_kind[4];
     uint64_t singular_matrices; /* transformed spheres whose matrix has det == 0 (:148) */
     int32_t  chunks;            /* row chunks the frame was traced in */
     int32_t  levels;            /* generations run (max_depth + 1) */
     float    ms_total;          /* device time of the last render, HIP events on its stream */
-    float    ms_closest;        /* RTX_F_TIME_KERNELS only: summed device time of the closest-hit launches */
-    float    ms_shadow;         /*                          ... of the shadow any-hit launches */
-    /* packet test: {waves, waves using it, 64-primitive batches tested, primitives kept} for the
-     * closest-hit kernel, then the same four for the shadow passes (non-thin generations only);
-     * RTX_F_PACKET_STATS only */
+    float    ms_closest;        /* RTX_F_TIME_KERNELS only: summed device time of the generation-0 closest-hit launches
+                                   (k_closest_f; with RTX_F_COUNT_TESTS / RTX_F_EXACT_ONLY: of every generation's) */
+    float    ms_shadow;         /*                          ... of the shadow any-hit launches (k_shadow_pass) */
+    /* RTX_F_PACKET_STATS only.  [0..3] closest-hit: generation 0 adds {waves, waves that made a packet,
+     * 64-record batches tested, primitives kept}, later generations {waves, lanes sent to the ordered scan
+     * | abnormal lanes << 32, list flushes, exact tests}.  [4..7] shadow pass: {lane blocks traced, blocks
+     * that made a packet | rays traced transposed << 32, 64-record batches tested, primitives kept} */
     uint64_t packet_stats[8];
     int32_t  launches_closest;  /* launches behind ms_closest / ms_shadow */
     int32_t  launches_shadow;
+    float    ms_closest_lanes;  /* RTX_F_TIME_KERNELS only: summed device time of the per-ray closest-hit launches of
+                                   generations >= 1 (k_closest_lanes) */
+    int32_t  launches_closest_lanes;
 } rtx_stats;
 
 enum {

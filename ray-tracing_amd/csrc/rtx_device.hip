@@ -1601,7 +1601,7 @@ struct rtx_context {
     std::vector<int> sb_kind;               // kind (0 sphere, 2 triangle) of each shadow-ordered primitive
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
-    std::vector<int> kev_kind;              // 0 closest, 1 shadow, per pair used by the last render
+    std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
     hipStream_t last_stream = nullptr;
     bool rendered = false;
     int nchunks = 0;
@@ -1926,7 +1926,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
-            if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(0); }
+            if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
             hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
             if (c->S.nl > 0 && (count || exact_only)) {
@@ -2099,6 +2099,7 @@ int rtx_context_stats(rtx_context* c, rtx_stats* s)
         float m = 0;
         HIPCHK(hipEventElapsedTime(&m, c->kev[2 * e], c->kev[2 * e + 1]));
         if (c->kev_kind[e] == 0) { s->ms_closest += m; s->launches_closest++; }
+        else if (c->kev_kind[e] == 2) { s->ms_closest_lanes += m; s->launches_closest_lanes++; }
         else { s->ms_shadow += m; s->launches_shadow++; }
     }
     return RTX_OK;

@@ -82,7 +82,8 @@ class Stats(C.Structure):
                 ("singular_matrices", C.c_uint64), ("chunks", C.c_int32), ("levels", C.c_int32),
                 ("ms_total", C.c_float), ("ms_closest", C.c_float), ("ms_shadow", C.c_float),
                 ("packet_stats", C.c_uint64 * 8),
-                ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32)]
+                ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32),
+                ("ms_closest_lanes", C.c_float), ("launches_closest_lanes", C.c_int32)]
 
     @property
     def rays_total(self):
