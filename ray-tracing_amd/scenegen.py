@@ -53,9 +53,13 @@ HEADER = ("camera 0 0 -1\n" "vrp 0 0 0\n" "vpn 0 0 -1\n" "up 0 1 0\n")  # bundle
 
 def write_scene(path, nspheres, ntriangles, lights, seed=SEED, zfar=-120.0, frac_affine=0.10,
                 frac_reflective=0.30, frac_refractive=0.0, ambient=(0.05, 0.05, 0.05),
-                radius=(0.3, 1.2), edge=2.0, box=(40.0, 25.0), znear=-20.0):
-    """Write one scene; returns the number of records.  `lights` is a list of (x,y,z,r,g,b)."""
+                radius=(0.3, 1.2), edge=2.0, box=(40.0, 25.0), znear=-20.0, affine="diag"):
+    """Write one scene; returns the number of records.  `lights` is a list of (x,y,z,r,g,b).
+    affine = "diag": scale matrices (the benchmark scenes); "general": rotation x scale matrices, one in 16
+    with a translation row and one in 32 singular (parity stress scenes; drawn from a second generator so
+    the other records do not change)."""
     rng = SplitMix64(seed)
+    rng2 = SplitMix64(seed ^ 0x5DEECE66D)
     lines = []
     for L in lights:
         lines.append("light " + _fs(L))
@@ -76,7 +80,22 @@ def write_scene(path, nspheres, ntriangles, lights, seed=SEED, zfar=-120.0, frac
             s = ("sphere %s %s %s %s %s %s %s 1.2 %d %s" %
                  (_fs(c[i]), _f(r[i]), _fs(col[i]), _fs(dif[i]), _fs(spe[i]), _f(refl[i]), _f(refr[i]),
                   1 if xf[i] else 0, _f(expo[i])))
-            if xf[i]:
+            if xf[i] and affine == "general":
+                q = rng2.uniform(-1, 1, 4)
+                q = q / max(float(np.linalg.norm(q)), 1e-6)
+                a, b, cc, d = (float(v) for v in q)
+                R = np.array([[a*a+b*b-cc*cc-d*d, 2*(b*cc-a*d), 2*(b*d+a*cc)],
+                              [2*(b*cc+a*d), a*a-b*b+cc*cc-d*d, 2*(cc*d-a*b)],
+                              [2*(b*d-a*cc), 2*(cc*d+a*b), a*a-b*b-cc*cc+d*d]])
+                M = R * np.asarray(sc[i], dtype=np.float64)[None, :]
+                kind = float(rng2.uniform(0, 1, 1)[0])
+                t = np.zeros(3)
+                if kind < 1.0 / 16:
+                    t = np.asarray(rng2.uniform(-0.5, 0.5, 3), dtype=np.float64)
+                elif kind < 1.0 / 16 + 1.0 / 32:
+                    M[2] = M[0] * 2.0  # singular
+                s += " " + " ".join(_f(v) for v in list(M.reshape(-1)) + list(t))
+            elif xf[i]:
                 s += " %s 0 0 0 %s 0 0 0 %s 0 0 0" % (_f(sc[i, 0]), _f(sc[i, 1]), _f(sc[i, 2]))
             lines.append(s)
     if ntriangles:

@@ -61,7 +61,7 @@ def test_context_reuse_and_device_output(rt, gpu):
     b = ctx.read_rgb8()
     s2 = ctx.stats()
     assert np.array_equal(a, b)
-    assert s1.rays_total == s2.rays_total and s1.launches_closest == 5 and s1.ms_total > 0
+    assert s1.rays_total == s2.rays_total and s1.launches_closest + s1.launches_closest_lanes == 5 and s1.ms_total > 0
     ctx.close()
 
 

@@ -70,3 +70,64 @@ def test_c4_crop_matches_oracle(rt, oracle, gpu, c4_scene):
     same = raw_equal_mask(raw_gpu, raw_cpu)
     print("c4 crop: %d of %d pixels bit-identical" % (int(same.sum()), same.size))
     assert same.mean() >= 0.999
+
+
+def test_culling_is_exact_on_4k_frame(rt, gpu, c4_scene):
+    """The benchmark frame itself (3840x2160, depth 5): packets, per-ray traversal, light-space binning and
+    side streams against the exact-only kernels that walk every primitive in file order."""
+    W, H = 3840, 2160
+    ra, sa = rt.render_rgb8(c4_scene, rt.Params.make(W, H, 4))
+    rb, sb = rt.render_rgb8(c4_scene, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert np.array_equal(ra, rb), "%d bytes differ" % int((ra != rb).sum())
+
+
+def test_culling_is_exact_across_segments(rt, gpu, tmp_path):
+    """45,000 primitives = two 32,768-primitive segments of the closest-hit hierarchy; 800x450 > 2^18 rays
+    so generation 0 runs the packet kernel."""
+    p = tmp_path / "seg.txt"
+    rt.scenegen.write_scene(str(p), 20000, 25000, rt.scenegen.lights_c4(), seed=77, frac_refractive=0.05,
+                            radius=(0.2, 0.7), edge=1.2)
+    sc = rt.load_scene(str(p))
+    W, H = 800, 450
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 2))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 2, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
+@pytest.mark.parametrize("size", [(960, 540), (200, 120)])
+def test_culling_is_exact_with_general_affine_matrices(rt, gpu, tmp_path, size):
+    """Half of the spheres affine with rotation x scale matrices, some with a translation row (never bounded:
+    always pass), some singular (zero-direction children): the world-space ellipsoid bounds, the strip test
+    of the shadow pass and the sticky-flag list of the per-ray traversal, against the exact-only kernels."""
+    p = tmp_path / "aff.txt"
+    rt.scenegen.write_scene(str(p), 3000, 3000, rt.scenegen.lights_c4(), seed=5, frac_affine=0.5,
+                            frac_reflective=0.5, frac_refractive=0.1, affine="general")
+    sc = rt.load_scene(str(p))
+    W, H = size
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 3))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 3, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
+def test_general_affine_scene_matches_oracle(rt, oracle, gpu, tmp_path):
+    """A generated scene the reference's authors never saw: 300 spheres (half affine, general matrices,
+    translation rows, singular ones) + 300 triangles, reflective and refractive, against the CPU oracle."""
+    p = tmp_path / "affo.txt"
+    rt.scenegen.write_scene(str(p), 300, 300, rt.scenegen.lights_c4(), seed=9, frac_affine=0.5, frac_reflective=0.5,
+                            frac_refractive=0.2, affine="general", radius=(1.0, 4.0), edge=8.0)
+    sc = rt.load_scene(str(p))
+    W, H = 160, 120
+    raw_gpu, st = rt.render_f32(sc, rt.Params.make(W, H, 4))
+    raw_cpu, cnt = oracle.render_f32(sc, W, H, 4)
+    assert st.rays_primary + st.rays_secondary == cnt.trace_calls
+    assert st.rays_shadow == cnt.shadow_rays and st.hits == cnt.hits
+    same = raw_equal_mask(raw_gpu, raw_cpu)
+    assert same.mean() >= 0.999, int((~same).sum())
+    rgb_gpu, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
+    rgb_cpu, _ = oracle.render_rgb8(sc, W, H, 4)
+    assert_rgb8_parity(rgb_gpu, rgb_cpu, "general affine")
