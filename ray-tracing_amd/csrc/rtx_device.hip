@@ -59,6 +59,7 @@ struct SceneDev {
     const rtx_xmatrix* sph_im;    // [ns]  precomputed inverseMatrix(mat)
     const rtx_sphere* sph;        // [ns]
     const float4* tri_hot;        // [nt*5]
+    const float4* phot;           // [(ns+nt)*5] one 80-byte hot record per primitive (rtx_pack.h, prim_hot)
     const rtx_triangle* tri;      // [nt]
     const rtx_light* lights;      // [nl]
     F3 ambient;
@@ -549,20 +550,26 @@ struct LexAcc {
     bool overflow;
 };
 
-// exact test of primitive k (per lane) with the order-independent update
+// exact test of primitive k (per lane) with the order-independent update.  The primitive's 80-byte hot
+// record (SceneDev::phot) comes in with five independent loads: one memory round trip per round of the
+// lockstep loop, where sph_hot -> sph_xf -> sph_im was a chain of three.
 __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
 {
+    const float4* p = S.phot + (size_t)k * 5;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
     if (k < S.ns) {
-        float4 hh = S.sph_hot[k];
-        int xf = S.sph_xf[k];
+        const bool xf = q4.x != 0.0f;
         F3 to = o, td = nd;
         if (xf) {
-            const rtx_xmatrix& im = S.sph_im[k];
+            rtx_xmatrix im;
+            im.a.x = q1.x; im.a.y = q1.y; im.a.z = q1.z; im.b.x = q1.w;
+            im.b.y = q2.x; im.b.z = q2.y; im.c.x = q2.z; im.c.y = q2.w;
+            im.c.z = q3.x; im.d.x = q3.y; im.d.y = q3.z; im.d.z = q3.w;
             to = inv_apply(o, im);
             td = normalized(inv_apply(d, im));
         }
         float t;
-        if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
+        if (sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t)) {
             if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
             if (xf) {
                 if (t < kMaxT) {
@@ -586,7 +593,12 @@ __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, 
             }
         }
     } else {
-        TriRec T = load_tri(S.tri_hot, k - S.ns);
+        TriRec T;
+        T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
+        T.vx = q1.x; T.vy = q1.y; T.vz = q1.z; T.area = q1.w;
+        T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
+        T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
+        T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
         float t, vd;
         if (triangle_test(o, d, T, t, vd)) {
             if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
@@ -1690,6 +1702,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&thot, P.tri_hot.size() * 5))) return rc;
         if (!P.tri_hot.empty()) HIPCHK(hipMemcpy(thot, P.tri_hot.data(), P.tri_hot.size() * sizeof(TriHot), hipMemcpyHostToDevice));
         c->S.tri_hot = thot;
+        float4* ph = nullptr;
+        if ((rc = c->dalloc(&ph, P.prim_hot.size() * 5))) return rc;
+        if (!P.prim_hot.empty()) HIPCHK(hipMemcpy(ph, P.prim_hot.data(), P.prim_hot.size() * sizeof(TriHot), hipMemcpyHostToDevice));
+        c->S.phot = ph;
         int* xf = nullptr; rtx_xmatrix* im = nullptr; rtx_sphere* sp = nullptr; rtx_triangle* tr = nullptr; rtx_light* lt = nullptr;
         if ((rc = c->upload(&xf, P.sph_xf))) return rc;
         if ((rc = c->upload(&im, P.sph_im))) return rc;

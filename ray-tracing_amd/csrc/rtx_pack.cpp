@@ -224,6 +224,17 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
     }
     for (int i = 0; i < sc.nlights; i++) P.lights.push_back(sc.lights[i]);
     P.max_fanout = fan;
+    for (size_t i = 0; i < P.sph.size(); i++) {
+        const SphHot& h = P.sph_hot[i];
+        const rtx_xmatrix& m = P.sph_im[i];
+        TriHot r = { { h.cx, h.cy, h.cz, h.r2,
+                       m.a.x, m.a.y, m.a.z, m.b.x,
+                       m.b.y, m.b.z, m.c.x, m.c.y,
+                       m.c.z, m.d.x, m.d.y, m.d.z,
+                       P.sph_xf[i] ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f } };
+        P.prim_hot.push_back(r);
+    }
+    for (const TriHot& t : P.tri_hot) P.prim_hot.push_back(t);
 
     // filter records.  guard = 16 x the extent of everything finite in the scene.
     double ext = 1.0;

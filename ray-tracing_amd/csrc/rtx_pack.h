@@ -91,6 +91,10 @@ struct PackedScene {
                                          // `transformed` flag quirk, :396-399, :443, :454)
     std::vector<rtx_sphere>  sph;        // raw records (materials, centre, radius, mat)
     std::vector<TriHot>      tri_hot;
+    // one 80-byte record per primitive (spheres first), fetched by the lanes that need it with five
+    // independent 16-byte loads: sphere { c, r*r | im.a, im.b.x | im.b.yz, im.c.xy | im.c.z, im.d | xf, 0, 0, 0 },
+    // triangle = its TriHot
+    std::vector<TriHot>      prim_hot;
     std::vector<rtx_triangle> tri;
     std::vector<rtx_light>   lights;
     // camera (raytracing.cpp:725-737)
