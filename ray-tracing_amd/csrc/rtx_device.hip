@@ -352,7 +352,7 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 // abnormal lane, or a cone wider than ~70 degrees, do not use it (they take the grouped loop).
 // ------------------------------------------------------------------------------------------------
 constexpr int kPacketDense = 20;  // more survivors than this in a batch of 64: use the grouped loop for the batch
-struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; bool ok; };
+struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; float c0; bool ok; };  // c0 = cos(theta), rounded down, before the widening by E
 
 __device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int m = 32; m; m >>= 1) v = fmaxf(v, __shfl_xor(v, m)); return v; }
@@ -392,6 +392,7 @@ __device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, 
     float c = wave_min(P.w.x * dd.x + P.w.y * dd.y + P.w.z * dd.z) - 4e-6f;  // cos(theta), rounded down
     bad = bad || !(c > 0.35f);
     c = fminf(c, 1.0f);
+    P.c0 = c;
     float sT = sqrtf(fmaxf(0.0f, 1.0f - c * c)) + 4e-6f;
     // widen by the filter's own angular tolerance (3.47e-3 rad) plus slack: E = 3.7e-3 rad
     const float cosE = 0.99999316f, sinE = 3.7e-3f;
@@ -1124,7 +1125,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
     asm volatile("" : "+v"(accinit));
     bool done = !live;
-    int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0;
+    int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0, pk_aff = 0;
     auto bcast4 = [](float4 v, int u) {
         float4 r;
         r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), u));
@@ -1198,8 +1199,8 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             // passes only if |p - c| <= R + tan(alpha) |p - o|, tan^2(alpha) <= 2^-13 + 2^-19.  So a sphere some
             // ray can pass has, on BOTH axes of an orthonormal pair around q_w,
             //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
-            //     T = R + rperp + (kappa (chord + 1e-5) + 0.0112)(|c - Lr| + Dmax') + rounding slack,
-            // kappa >= cond(A) from the record.  Everything else is skipped for the whole block.
+            //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
+            // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
             if (!out && S.naff > 0) {
                 const F3 Lr = one_light ? apex : P.co;
                 const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 const float Dmin = wave_min(D), Dmax = wave_max(D);
                 const float Dfar = wave_max(sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
                 const float rperp = wave_max(sqrtf(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
-                const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * sqrtf(P.cosT2))) * 1.0001f + 2e-5f;
+                const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * P.c0)) * 1.0001f + 2e-5f;  // |ld - w| over the block
                 for (int a0 = part * 64; a0 < S.naff && !out; a0 += 64 * parts) {
                     const int ai = min(a0 + lane, S.naff - 1);
                     const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
@@ -1218,13 +1219,16 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     bool pass = a0 + lane < S.naff;
                     {
                         const F3 w = P.w;
+                        // rows of A: ra = (m0.x m0.y m0.z), rb = (m0.w m1.x m1.y), rc = (m1.z m1.w m2.x); q = w A
                         float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
                         float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
                         float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
                         const float qn = sqrtf(qx * qx + qy * qy + qz * qz);
                         const float R = sqrtf(-m3.x) * 1.00001f;   // +inf for records that always pass, NaN never arises (m3.x <= 0)
-                        const float kappa = m3.z;
-                        if (qn > 1e-18f && qn < 1e18f && R < 1e18f && kappa >= 1.0f && kappa < 1e6f) {
+                        const float nF = sqrtf(m0.x * m0.x + m0.y * m0.y + m0.z * m0.z + m0.w * m0.w + m1.x * m1.x + m1.y * m1.y +
+                                               m1.z * m1.z + m1.w * m1.w + m2.x * m2.x) * 1.00001f;  // >= ||A||_2
+                        const float qlow = qn * 0.99999f - chord * nF;  // <= |ld A| for every ray of the block
+                        if (qn < 1e18f && R < 1e18f && nF < 1e18f && qlow > 0.25f * qn && qlow > 1e-18f) {
                             const float inv = 1.0f / qn;
                             qx *= inv; qy *= inv; qz *= inv;
                             // orthonormal pair around q (Duff et al.), good to ~1e-6
@@ -1234,17 +1238,26 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                             const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
                             const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
                             const F3 E = f3(m2.y - Lr.x, m2.z - Lr.y, m2.w - Lr.z);
-                            const float dist = sqrtf(E.x * E.x + E.y * E.y + E.z * E.z);
-                            const float T = (R + rperp + (kappa * chord + 0.0112f) * (dist + Dfar)) * 1.0001f + 1e-5f * (dist + Dfar);
+                            // |c - o| <= far for every ray of the block: o = Lr - D w + e
+                            const F3 f1 = f3(E.x + Dmin * w.x, E.y + Dmin * w.y, E.z + Dmin * w.z);
+                            const F3 f2 = f3(E.x + Dmax * w.x, E.y + Dmax * w.y, E.z + Dmax * w.z);
+                            const float far = sqrtf(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + rperp;
+                            // a.(delta A) = delta.(A a^T): |.| <= chord |A a^T|; 1e-5 covers the pair's own orthogonality error
+                            const F3 v1 = f3(m0.x * ax1.x + m0.y * ax1.y + m0.z * ax1.z, m0.w * ax1.x + m1.x * ax1.y + m1.y * ax1.z, m1.z * ax1.x + m1.w * ax1.y + m2.x * ax1.z);
+                            const F3 v2 = f3(m0.x * ax2.x + m0.y * ax2.y + m0.z * ax2.z, m0.w * ax2.x + m1.x * ax2.y + m1.y * ax2.z, m1.z * ax2.x + m1.w * ax2.y + m2.x * ax2.z);
+                            const float g1 = (chord * sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) + 1e-5f * nF) / qlow;
+                            const float g2 = (chord * sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) + 1e-5f * nF) / qlow;
+                            const float base_T = (R + rperp + 0.0112f * far) * 1.0001f + 1e-5f * (far + Dfar);
+                            const float T1 = base_T + g1 * far * 1.0001f, T2 = base_T + g2 * far * 1.0001f;
                             const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
                             const float t2 = ax2.x * w.x + ax2.y * w.y + ax2.z * w.z, e2 = ax2.x * E.x + ax2.y * E.y + ax2.z * E.z;
                             const float lo1 = fminf(-Dmin * t1, -Dmax * t1), hi1 = fmaxf(-Dmin * t1, -Dmax * t1);
                             const float lo2 = fminf(-Dmin * t2, -Dmax * t2), hi2 = fmaxf(-Dmin * t2, -Dmax * t2);
-                            if (e1 < lo1 - T || e1 > hi1 + T || e2 < lo2 - T || e2 > hi2 + T) pass = false;
+                            if (e1 < lo1 - T1 || e1 > hi1 + T1 || e2 < lo2 - T2 || e2 > hi2 + T2) pass = false;
                         }
                     }
                     unsigned long long am = __ballot(pass);
-                    pk_batches++; pk_surv += __popcll(am);
+                    pk_batches++; pk_aff += __popcll(am);
                     while (am) {
                         const int u = __ffsll((long long)am) - 1;
                         am &= am - 1;
@@ -1297,7 +1310,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     }
     if (S.pstat && lane == 0) {
         atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
-        atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv);
+        atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv + ((unsigned long long)pk_aff << 32));
     }
     if (live && done) lit[id] = 0;
 }
