@@ -1320,7 +1320,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
 // and the serial walk per wave -- what bounds the run time when there are fewer waves than SIMDs can hold --
 // is kSplit times shorter.
 constexpr int kSplit = 4;
-constexpr int kSplitRays = 1 << 20;
+constexpr int kSplitRays = 1 << 21;
 
 __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
 {

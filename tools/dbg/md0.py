@@ -5,9 +5,11 @@ p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
 md = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-ctx = rt.Context(sc, rt.Params.make(3840, 2160, md, flags=rt.host.F_TIME_KERNELS))
-for _ in range(3):
-    ctx.render()
-st = ctx.stats()
-print("md", md, "ms", st.ms_total, "closest", st.ms_closest, "shadow", st.ms_shadow)
-ctx.close()
+for (W, H) in ((640, 480), (1280, 720), (1920, 1080), (3840, 2160)):
+    ctx = rt.Context(sc, rt.Params.make(W, H, md, flags=rt.host.F_TIME_KERNELS))
+    for _ in range(3):
+        ctx.render()
+    st = ctx.stats()
+    print("%dx%d md %d: frame %.3f ms, closest_f %.3f, lanes %.3f (%d launches), shadow %.3f (%d launches), rays %d" % (
+        W, H, md, st.ms_total, st.ms_closest, st.ms_closest_lanes, st.launches_closest_lanes, st.ms_shadow, st.launches_shadow, st.rays_total))
+    ctx.close()
