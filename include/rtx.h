@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 0x00010000u
+#define RTX_ABI_VERSION 0x00020000u
 
 /* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
  * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
@@ -64,6 +64,19 @@ typedef struct rtx_triangle {
 /* raytracing.cpp:62-68  `struct light` (24 B) */
 typedef struct rtx_light { rtx_vec3 point, color; } rtx_light;
 
+/* raytracing.cpp:71-80  `struct polygon` with its std::vector<V> flattened (84 B): the vertices of
+ * polygon i are rtx_scene.polygon_vertices[first_vertex .. first_vertex + numvertices).  `normal` and
+ * `centerPoint` are what parseinput computes (:929-933, :957-959).  Traced after the triangles
+ * (:421-434); never a shadow caster (:569-589 test spheres and triangles only). */
+typedef struct rtx_polygon {
+    int32_t  numvertices;
+    int32_t  first_vertex;
+    rtx_vec3 color, speccoeff, diffcolor;
+    rtx_vec3 normal;
+    rtx_vec3 centerPoint;
+    float    reflectivity, transparency, refractive_index, specexpo;
+} rtx_polygon;
+
 /* The reference's globals (:98-110) as one read-only view.  The caller owns every pointer;
  * the library copies what it needs during the call that receives the view. */
 typedef struct rtx_scene {
@@ -73,8 +86,10 @@ typedef struct rtx_scene {
     const rtx_light*    lights;     int32_t nlights;      /* :102, :110 */
     rtx_vec3 camera, vrp, vpn, up;                        /* :103  `vcs` */
     rtx_vec3 ambient;                                     /* :104 */
-    int32_t  npolygons_ignored;  /* polygon records (:101, :910-967) the loader consumed but did
-                                    not keep: polygons are not traced yet */
+    const rtx_polygon*  polygons;   int32_t npolygons;    /* :101, :109 */
+    const rtx_vec3*     polygon_vertices; int32_t npolygon_vertices;
+    int32_t  npolygons_dropped;  /* polygon records the loader consumed but did not keep, as parseinput does
+                                    when the coplanarity check fails (:945-948, :962) */
 } rtx_scene;
 
 /* The reference's compile-time constants as run-time parameters, plus the band decomposition.
@@ -208,7 +223,8 @@ int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t cap
 
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),
- * records zero-filled before parsing.  Polygon records are consumed and dropped.
+ * records zero-filled before parsing.  Polygons keep parseinput's rules: normal from the
+ * first three vertices, exact-equality coplanarity check, centroid (:913-966).
  * The returned scene owns its arrays; release with rtx_scene_free. */
 int  rtx_scene_load(const char* path, rtx_scene** out);
 void rtx_scene_free(rtx_scene* scene);

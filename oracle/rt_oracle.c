@@ -160,6 +160,43 @@ int orc_intersect_triangle(V o, V dir, const rtx_triangle* s, V* normal, float* 
     return 1;
 }
 
+/* rt.cpp:132-135 */
+static V cross(V u, V v) { return mkv(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+
+/* rt.cpp:289-300: fan of triangles (point, v_i, v_prev), areas summed in float */
+float orc_find_area_polygon(const rtx_polygon* p, const rtx_vec3* verts, V point)
+{
+    float area = 0.0;
+    int n = p->numvertices;
+    for (int i = 0, j = n - 1; i < n; j = i++) {
+        V u = mkv(point.x - verts[i].x, point.y - verts[i].y, point.z - verts[i].z);
+        V v = mkv(point.x - verts[j].x, point.y - verts[j].y, point.z - verts[j].z);
+        V c = cross(u, v);
+        float temparea = 0.5 * sqrtf(dot(c, c));
+        area += temparea;
+    }
+    return area;
+}
+
+/* rt.cpp:303-325 as it behaves once it compiles: `dotproduct == 0` (:305) compares the
+ * FUNCTION with 0 and is never true; `dotproduct > 0` (:308) does not compile and is `true` in the
+ * one-token fix oracle/Makefile applies (what gcc 4.8 made of it), so the stored normal is ALWAYS negated. */
+int orc_intersect_polygon(V o, V dir, const rtx_polygon* p, const rtx_vec3* verts, V* normal, float* t)
+{
+    if (p->numvertices < 1) return 0; /* vertices[0] does not exist (:312 would be out of bounds) */
+    V n = p->normal;
+    n.x *= -1; n.y *= -1; n.z *= -1;
+    *normal = n;
+    float d = -1 * (dot(n, verts[0]));
+    *t = -(dot(n, o) + d) / dot(n, dir);
+    if (*t < 0) return 0;
+    V point = mkv(o.x + dir.x * *t, o.y + dir.y * *t, o.z + dir.z * *t);
+    float totalArea = orc_find_area_polygon(p, verts, p->centerPoint);
+    float sumArea = orc_find_area_polygon(p, verts, point);
+    if (fabsf(totalArea - sumArea) > 0.001) return 0; /* float abs, double compare */
+    return 1;
+}
+
 /* The reflect / refract block shared (textually duplicated in the reference) by spheres
  * (rt.cpp:462-494, with rd = traydir) and triangles (:497-525, with rd = raydir).
  * invert_eta is the sphere-only `insphere` rule (:477-479). */
@@ -199,15 +236,16 @@ static void secondary(const rtx_scene* sc, int max_depth, int depth, orc_counts*
     }
 }
 
-/* rt.cpp:371-647 without the polygon branches */
+/* rt.cpp:371-647 */
 V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int depth, orc_counts* cnt)
 {
     float nearest = MAX_T;
     const rtx_sphere* s = NULL;
     const rtx_triangle* tr = NULL;
+    const rtx_polygon* pg = NULL;
     V pix, normal = mkv(0, 0, 0);
     int objectfound = 0, transformed = 0;
-    int ob = 0; /* 0 none, 1 sphere, 2 triangle */
+    int ob = 0; /* 0 none, 1 sphere, 2 triangle, 3 polygon */
     if (cnt) cnt->trace_calls++;
     pix.x = pix.y = pix.z = 0.4;
     /* :382-404 */
@@ -248,6 +286,22 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
             }
         }
     }
+    /* :421-434 */
+    for (int i = 0; i < sc->npolygons; i++) {
+        float t = MAX_T;
+        V normaltemp;
+        const rtx_polygon* p = &sc->polygons[i];
+        if (orc_intersect_polygon(rayorigin, raydir, p, sc->polygon_vertices + p->first_vertex, &normaltemp, &t)) {
+            if (t < nearest) {
+                nearest = t;
+                pg = p;
+                normal = normaltemp;
+                ob = 3;
+                objectfound = 1;
+                transformed = 0;
+            }
+        }
+    }
     if (!objectfound) return pix; /* :436-438, no ambient */
     if (cnt) cnt->hits++;
     V intpoint = mkv(rayorigin.x + nearest * raydir.x, rayorigin.y + nearest * raydir.y, rayorigin.z + nearest * raydir.z);
@@ -267,9 +321,12 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
             }
             secondary(sc, max_depth, depth, cnt, traydir, normal, intpoint, bias,
                       s->reflectivity, s->transparency, s->refractive_index, s->color, insphere, &pix);
-        } else {
+        } else if (ob == 2) {
             secondary(sc, max_depth, depth, cnt, raydir, normal, intpoint, bias,
                       tr->reflectivity, tr->transparency, tr->refractive_index, tr->color, 0, &pix);
+        } else { /* :527-556: the triangle block again with the polygon's material */
+            secondary(sc, max_depth, depth, cnt, raydir, normal, intpoint, bias,
+                      pg->reflectivity, pg->transparency, pg->refractive_index, pg->color, 0, &pix);
         }
     }
     /* :560-641 */
@@ -310,8 +367,10 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
                 orc_normalize(&ldir);
                 orc_normalize(&vdir);
                 speccoeff = s->speccoeff; diffcolor = s->diffcolor; specexpo = s->specexpo;
-            } else { /* :613-626: no normalisation of either direction */
+            } else if (ob == 2) { /* :613-626: no normalisation of either direction */
                 speccoeff = tr->speccoeff; diffcolor = tr->diffcolor; specexpo = tr->specexpo;
+            } else { /* :627-639: the same form for polygons */
+                speccoeff = pg->speccoeff; diffcolor = pg->diffcolor; specexpo = pg->specexpo;
             }
             float ndoti2 = 2 * (dot(ldir, normal));
             V reflectedray = mkv(ndoti2 * normal.x - ldir.x, ndoti2 * normal.y - ldir.y, ndoti2 * normal.z - ldir.z);

@@ -32,7 +32,10 @@ rtx_vec3    orc_invtransform(rtx_vec3 v, rtx_xmatrix m, int transpose);
 /* rt.cpp:202-233, :329-366 */
 int orc_intersect_sphere(rtx_vec3 o, rtx_vec3 d, const rtx_sphere* s, rtx_vec3* normal, float* t0, float* t1);
 int orc_intersect_triangle(rtx_vec3 o, rtx_vec3 d, const rtx_triangle* s, rtx_vec3* normal, float* t);
-/* rt.cpp:371-647 (polygon branches excluded: out of scope) */
+/* rt.cpp:289-325 */
+float orc_find_area_polygon(const rtx_polygon* p, const rtx_vec3* verts, rtx_vec3 point);
+int orc_intersect_polygon(rtx_vec3 o, rtx_vec3 d, const rtx_polygon* p, const rtx_vec3* verts, rtx_vec3* normal, float* t);
+/* rt.cpp:371-647 */
 rtx_vec3 orc_raytrace(const rtx_scene* sc, int max_depth, rtx_vec3 o, rtx_vec3 d, int depth, orc_counts* cnt);
 /* rt.cpp:792-794: one channel */
 unsigned char orc_quantise(float v);

@@ -54,6 +54,9 @@ constexpr int kTFlag = 1 << 30;      // the reference's `transformed` flag, carr
 // ------------------------------------------------------------------------------------------------
 struct SceneDev {
     int ns, nt, nl;
+    int np;                       // polygons: primitive index ns + nt + i, traced after the triangles (:421-434)
+    const rtx_polygon* poly;      // [np] raw records (materials)
+    const float4* poly_verts;     // vertices, x y z 0; a polygon's run starts at its hot record's first_vertex
     const float4* sph_hot;        // [ns]  cx cy cz r^2
     const int* sph_xf;            // [ns]
     const rtx_xmatrix* sph_im;    // [ns]  precomputed inverseMatrix(mat)
@@ -113,6 +116,31 @@ __device__ __forceinline__ TriRec load_tri(const float4* hot, int i)
     T.v1y = d.x; T.v1z = d.y; T.v2x = d.z; T.v2y = d.w;
     T.v2z = e.x; T.ex = e.y; T.ey = e.z; T.ez = e.w;
     return T;
+}
+
+// raytracing.cpp:303-325 with the ray-independent head precomputed (rtx_pack.cpp): q0 = { n, d } with n the
+// stored normal NEGATED (always: :308 is `true` once it compiles; :305 compares a function
+// with 0 and never fires), q1 = { area of the centroid fan, first vertex, vertex count, - }.
+__device__ __forceinline__ bool polygon_test(F3 o, F3 dir, float4 q0, float4 q1, const float4* verts, float& t)
+{
+    const int first = __float_as_int(q1.y), cnt = __float_as_int(q1.z);
+    if (cnt < 1) return false;
+    t = -((q0.x * o.x + q0.y * o.y + q0.z * o.z) + q0.w) / (q0.x * dir.x + q0.y * dir.y + q0.z * dir.z);  // :313
+    if (t < 0.0f) return false;
+    const float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+    float sum = 0.0f;  // findAreaPolygon(p, point), :289-300
+    float4 vj = verts[first + cnt - 1];
+    for (int i = 0; i < cnt; i++) {
+        const float4 vi = verts[first + i];
+        const float ux = px - vi.x, uy = py - vi.y, uz = pz - vi.z;
+        const float vx = px - vj.x, vy = py - vj.y, vz = pz - vj.z;
+        const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+        const float temparea = 0.5f * sqrtf(cx * cx + cy * cy + cz * cz);
+        sum += temparea;
+        vj = vi;
+    }
+    if ((double)fabsf(q1.x - sum) > 0.001) return false;  // float abs, compared as double (:322)
+    return true;
 }
 
 // Slot allocation for a compacted queue: one atomicAdd per wavefront (64-bit ballot + mbcnt
@@ -235,6 +263,19 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
             }
         }
     }
+    for (int k = 0; k < S.np; k++) {  // :421-434
+        const float4* p = S.phot + (size_t)(S.ns + S.nt + k) * 5;
+        float t = 0.0f;
+        bool h = polygon_test(o, d, p[0], p[1], S.poly_verts, t);
+        if (COUNT) cnt[2]++;  // counted with the full-path triangle tests
+        if (h) {
+            if (t < nearest) {
+                nearest = t;
+                best = S.ns + S.nt + k;
+                tflag = 0;  // :432
+            }
+        }
+    }
     L.t[i] = nearest;
     L.prim[i] = (best < 0) ? -1 : (best | tflag);
     }
@@ -325,10 +366,16 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
         if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) { h.tflag = kTFlag; h.txf = t; } }
         }
-    } else {
+    } else if (k < S.ns + S.nt) {
         TriRec T = load_tri(S.tri_hot, k - S.ns);
         float t, vd;
         if (triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    } else {
+        const float4* p = S.phot + (size_t)k * 5;
+        float t;
+        if (polygon_test(o, d, p[0], p[1], S.poly_verts, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
     }
@@ -456,7 +503,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
     const Packet P = make_packet(o, nd, live, abn);
     int pk_batches = 0, pk_surv = 0;
-    const int nprim = S.ns + S.nt;
+    const int nprim = S.ns + S.nt + S.np;
     // this wave's bitmap of candidate primitives of the current segment (wave-private LDS: the wave's
     // DS operations execute in issue order, the fences only pin the compiler's ordering)
     volatile unsigned* bm = reinterpret_cast<volatile unsigned*>(tile) + (threadIdx.x >> 6) * (kSegPrims / 32);
@@ -593,6 +640,11 @@ __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, 
                     if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
             }
         }
+    } else if (k >= S.ns + S.nt) {
+        float t;
+        if (polygon_test(o, d, q0, q1, S.poly_verts, t)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+        }
     } else {
         TriRec T;
         T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
@@ -726,7 +778,7 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
     if (__any(slow)) {
         HitAcc hs;
         hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
-        const int nprim = S.ns + S.nt;
+        const int nprim = S.ns + S.nt + S.np;
         for (int k = 0; k < nprim; k++) {
             const float4 b = S.bounds[k];
             if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
@@ -785,7 +837,7 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     asm volatile("" : "+v"(accinit));
     HitAcc h;
     h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
-    const int nprim = S.ns + S.nt;
+    const int nprim = S.ns + S.nt + S.np;
     const int SL = ((nprim + kGroup - 1) / kGroup + 3) / 4 * kGroup;  // primitives per slice, whole groups
     const int p0 = min(w * SL, nprim), p1 = min(p0 + SL, nprim);
     const int T = (SL + kThinTile - 1) / kThinTile;
@@ -1367,13 +1419,18 @@ __global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelD
             normal = sphere_normal(to, td, nearest, s);
             if (s.istransformed) normal = inv_apply_normal(normal, im);
             reflectivity = s.reflectivity; transparency = s.transparency; ri = s.refractive_index;
-        } else {
+        } else if (prim < S.ns + S.nt) {
             const float4* p = S.tri_hot + (size_t)(prim - S.ns) * 5;
             float4 q0 = p[0];
             float vd = q0.x * d.x + q0.y * d.y + q0.z * d.z;
             normal = (vd > 0.0f) ? f3(-q0.x, -q0.y, -q0.z) : f3(q0.x, q0.y, q0.z);  // :343-347
             const rtx_triangle& t = S.tri[prim - S.ns];
             reflectivity = t.reflectivity; transparency = t.transparency; ri = t.refractive_index;
+        } else {
+            const float4 q0 = S.phot[(size_t)prim * 5];
+            normal = f3(q0.x, q0.y, q0.z);  // :311: the stored normal, negated
+            const rtx_polygon& g = S.poly[prim - S.ns - S.nt];
+            reflectivity = g.reflectivity; transparency = g.transparency; ri = g.refractive_index;
         }
         ip = f3(o.x + nearest * d.x, o.y + nearest * d.y, o.z + nearest * d.z);  // :440
         if (tflag) ip = fwd_apply(ip, S.sph[prim].mat);                          // :441-444
@@ -1489,10 +1546,14 @@ __global__ __launch_bounds__(kBlock) void k_unwind(SceneDev S, LevelDev L, Level
         color = f3(s.color); spec = f3(s.speccoeff); diff = f3(s.diffcolor);
         transparency = s.transparency; specexpo = s.specexpo;
         xf = s.istransformed != 0;
-    } else {
+    } else if (prim < S.ns + S.nt) {
         const rtx_triangle& t = S.tri[prim - S.ns];
         color = f3(t.color); spec = f3(t.speccoeff); diff = f3(t.diffcolor);
         transparency = t.transparency; specexpo = t.specexpo;
+    } else {  // :527-556, :627-639: the triangle forms with the polygon's material
+        const rtx_polygon& g = S.poly[prim - S.ns - S.nt];
+        color = f3(g.color); spec = f3(g.speccoeff); diff = f3(g.diffcolor);
+        transparency = g.transparency; specexpo = g.specexpo;
     }
     F3 pix = f3(0.0f, 0.0f, 0.0f);
     float fres = L.n_fres[j];
@@ -1658,7 +1719,14 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
     if (sc->nspheres < 0 || sc->ntriangles < 0 || sc->nlights < 0) return RTX_E_INVALID_ARG;
     if ((sc->nspheres && !sc->spheres) || (sc->ntriangles && !sc->triangles) || (sc->nlights && !sc->lights))
         return RTX_E_INVALID_ARG;
-    if ((int64_t)sc->nspheres + sc->ntriangles >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
+    if (sc->npolygons < 0 || sc->npolygon_vertices < 0) return RTX_E_INVALID_ARG;
+    if ((sc->npolygons && !sc->polygons) || (sc->npolygon_vertices && !sc->polygon_vertices)) return RTX_E_INVALID_ARG;
+    for (int i = 0; i < sc->npolygons; i++) {
+        const rtx_polygon& g = sc->polygons[i];
+        if (g.numvertices < 0 || g.first_vertex < 0 || (int64_t)g.first_vertex + g.numvertices > (int64_t)sc->npolygon_vertices)
+            return RTX_E_INVALID_ARG;
+    }
+    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
     if (sc->nlights > 65535) return RTX_E_TOO_LARGE;  // gridDim.y
     int nr = p->nranks <= 1 ? 1 : p->nranks;
     int rk = p->nranks <= 1 ? 0 : p->rank;
@@ -1726,6 +1794,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->upload(&tr, P.tri))) return rc;
         if ((rc = c->upload(&lt, P.lights))) return rc;
         c->S.sph_xf = xf; c->S.sph_im = im; c->S.sph = sp; c->S.tri = tr; c->S.lights = lt;
+        {
+            rtx_polygon* pg = nullptr; float* pv = nullptr;
+            if ((rc = c->upload(&pg, P.poly))) return rc;
+            if ((rc = c->upload(&pv, P.poly_verts))) return rc;
+            c->S.poly = pg; c->S.poly_verts = reinterpret_cast<const float4*>(pv); c->S.np = (int)P.poly.size();
+        }
         c->S.ns = (int)P.sph.size(); c->S.nt = (int)P.tri.size(); c->S.nl = (int)P.lights.size();
         c->S.ambient = {P.ambient.x, P.ambient.y, P.ambient.z};
         static_assert(sizeof(BoundSphere) == sizeof(float4), "filter record is one float4");

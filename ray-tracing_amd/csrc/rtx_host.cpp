@@ -3,6 +3,7 @@
 // PPM writer (:786-797), band arithmetic, error strings.  No device code here.
 #include "rtx.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -30,7 +31,16 @@ struct OwnedScene {
     std::vector<rtx_triangle> triangles;
     std::vector<rtx_plane> planes;
     std::vector<rtx_light> lights;
+    std::vector<rtx_polygon> polygons;
+    std::vector<rtx_vec3> polygon_vertices;
 };
+
+// raytracing.cpp:116-125
+inline void normalize_v(rtx_vec3& v)
+{
+    float n = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (n > 0.0f) { v.x = v.x / n; v.y = v.y / n; v.z = v.z / n; }
+}
 
 }  // namespace
 
@@ -107,14 +117,57 @@ int rtx_scene_load(const char* path, rtx_scene** out)
             r.v3(t.speccoeff);
             r.in >> t.reflectivity >> t.transparency >> t.refractive_index >> t.specexpo;
             sc->triangles.push_back(t);
-        } else if (kind == "polygon") {  // :910-967: tokens consumed so later records line up; record dropped
-            int nv = 0;
-            r.in >> nv;
-            rtx_vec3 skip;
-            for (int k = 0; k < nv && r.in; k++) r.v3(skip);
-            float m;
-            for (int k = 0; k < 13; k++) r.f(m);
-            dropped_polygons++;
+        } else if (kind == "polygon") {  // :910-967
+            rtx_polygon p;
+            std::memset(&p, 0, sizeof p);
+            r.in >> p.numvertices;
+            // the reference's `while (n--)` never ends for a negative count and allocates without bound for a
+            // huge one: both are refused here instead
+            if (p.numvertices < 0 || p.numvertices > (1 << 20)) { delete sc; return RTX_E_TOO_LARGE; }
+            int n = p.numvertices;
+            p.first_vertex = (int32_t)sc->polygon_vertices.size();
+            rtx_vec3 center = {0.0f, 0.0f, 0.0f};
+            rtx_vec3 normal = {0.0f, 0.0f, 0.0f};  // indeterminate in the reference below 3 vertices (F5 rule: zero)
+            bool correct = true;
+            const size_t v0 = sc->polygon_vertices.size();
+            while (n--) {
+                rtx_vec3 side = {0.0f, 0.0f, 0.0f};
+                r.v3(side);
+                center.x += side.x; center.y += side.y; center.z += side.z;
+                sc->polygon_vertices.push_back(side);
+                const rtx_vec3* vv = sc->polygon_vertices.data() + v0;
+                const size_t cnt = sc->polygon_vertices.size() - v0;
+                if (n == p.numvertices - 3) {  // :925-934
+                    rtx_vec3 u = {vv[0].x - vv[1].x, vv[0].y - vv[1].y, vv[0].z - vv[1].z};
+                    rtx_vec3 v = {vv[0].x - vv[2].x, vv[0].y - vv[2].y, vv[0].z - vv[2].z};
+                    normal.x = u.y * v.z - u.z * v.y;
+                    normal.y = u.z * v.x - u.x * v.z;
+                    normal.z = u.x * v.y - u.y * v.x;
+                    normalize_v(normal);
+                }
+                if (n < p.numvertices - 3) {   // :936-949: exact float equality of the two unit normals, or of one and the other's negation
+                    rtx_vec3 u = {vv[0].x - vv[1].x, vv[0].y - vv[1].y, vv[0].z - vv[1].z};
+                    rtx_vec3 v = {vv[0].x - vv[cnt - 1].x, vv[0].y - vv[cnt - 1].y, vv[0].z - vv[cnt - 1].z};
+                    rtx_vec3 tn = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+                    normalize_v(tn);
+                    bool same = (normal.x == tn.x && normal.y == tn.y && normal.z == tn.z) ||
+                                (-1 * normal.x == tn.x && -1 * normal.y == tn.y && -1 * normal.z == tn.z);
+                    if (!same) correct = false;
+                }
+            }
+            center.x = center.x / p.numvertices; center.y = center.y / p.numvertices; center.z = center.z / p.numvertices;  // :957
+            p.centerPoint = center;
+            p.normal = normal;
+            r.v3(p.color);
+            r.v3(p.diffcolor);
+            r.v3(p.speccoeff);
+            r.in >> p.reflectivity >> p.transparency >> p.refractive_index >> p.specexpo;
+            if (correct) {
+                sc->polygons.push_back(p);
+            } else {  // :962: the record is consumed but not kept
+                sc->polygon_vertices.resize(v0);
+                dropped_polygons++;
+            }
         } else if (kind == "light") {  // :968-976
             rtx_light l;
             std::memset(&l, 0, sizeof l);
@@ -131,7 +184,11 @@ int rtx_scene_load(const char* path, rtx_scene** out)
     sc->view.nplanes = (int32_t)sc->planes.size();
     sc->view.lights = sc->lights.empty() ? nullptr : sc->lights.data();
     sc->view.nlights = (int32_t)sc->lights.size();
-    sc->view.npolygons_ignored = dropped_polygons;
+    sc->view.polygons = sc->polygons.empty() ? nullptr : sc->polygons.data();
+    sc->view.npolygons = (int32_t)sc->polygons.size();
+    sc->view.polygon_vertices = sc->polygon_vertices.empty() ? nullptr : sc->polygon_vertices.data();
+    sc->view.npolygon_vertices = (int32_t)sc->polygon_vertices.size();
+    sc->view.npolygons_dropped = dropped_polygons;
     *out = &sc->view;
     return RTX_OK;
 }

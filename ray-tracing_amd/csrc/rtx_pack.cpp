@@ -235,6 +235,36 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
         P.prim_hot.push_back(r);
     }
     for (const TriHot& t : P.tri_hot) P.prim_hot.push_back(t);
+    for (int i = 0; i < sc.npolygons; i++) {
+        const rtx_polygon& pg = sc.polygons[i];
+        P.poly.push_back(pg);
+        const rtx_vec3* vv = sc.polygon_vertices + pg.first_vertex;
+        const int nv = pg.numvertices;
+        // intersectpolygon's ray-independent head (:309-312, :320), in its float expression order.  With the
+        // one-token fix that makes :308 compile the stored normal is ALWAYS negated.
+        rtx_vec3 n = pg.normal;
+        n.x *= -1; n.y *= -1; n.z *= -1;
+        float d = 0.0f, total = 0.0f;
+        if (nv >= 1) {
+            d = -1 * (dot(n, vv[0]));
+            for (int a = 0, b = nv - 1; a < nv; b = a++) {  // findAreaPolygon(p, p.centerPoint), :289-300
+                rtx_vec3 u = { pg.centerPoint.x - vv[a].x, pg.centerPoint.y - vv[a].y, pg.centerPoint.z - vv[a].z };
+                rtx_vec3 v = { pg.centerPoint.x - vv[b].x, pg.centerPoint.y - vv[b].y, pg.centerPoint.z - vv[b].z };
+                rtx_vec3 c = { u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x };
+                float temparea = 0.5f * std::sqrt(dot(c, c));
+                total += temparea;
+            }
+        }
+        int32_t first = (int32_t)(P.poly_verts.size() / 4), cnt = nv;
+        float ff, fc;
+        std::memcpy(&ff, &first, 4);
+        std::memcpy(&fc, &cnt, 4);
+        TriHot r = { { n.x, n.y, n.z, d, total, ff, fc, 0.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 } };
+        P.prim_hot.push_back(r);
+        for (int a = 0; a < nv; a++) { P.poly_verts.push_back(vv[a].x); P.poly_verts.push_back(vv[a].y); P.poly_verts.push_back(vv[a].z); P.poly_verts.push_back(0.0f); }
+        int f = (pg.reflectivity > 0 ? 1 : 0) + (pg.transparency > 0 ? 1 : 0);
+        if (f > P.max_fanout) P.max_fanout = f;
+    }
 
     // filter records.  guard = 16 x the extent of everything finite in the scene.
     double ext = 1.0;
@@ -246,6 +276,7 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
     for (const rtx_triangle& t : P.tri)
         for (const rtx_vec3* v : {&t.u, &t.v, &t.w}) { grow(v->x); grow(v->y); grow(v->z); }
     for (const rtx_light& l : P.lights) { grow(l.point.x); grow(l.point.y); grow(l.point.z); }
+    for (float v : P.poly_verts) grow(v);
     grow(sc.camera.x); grow(sc.camera.y); grow(sc.camera.z);
     grow(sc.vrp.x); grow(sc.vrp.y); grow(sc.vrp.z);
     double guard = 16.0 * ext;
@@ -255,7 +286,11 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
         P.bounds.push_back(P.sph[i].istransformed ? bound_sphere_affine(P.sph[i], P.sph_im[i], guard)
                                                   : bound_sphere_plain(P.sph[i]));
     for (size_t i = 0; i < P.tri.size(); i++) P.bounds.push_back(bound_sphere_triangle(P.tri[i], guard));
+    // polygons are not bounded yet: every ray takes their exact test (records that always pass)
+    for (size_t i = 0; i < P.poly.size(); i++) P.bounds.push_back({0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()});
     P.bounds_shadow = P.bounds;
+    for (size_t i = 0; i < P.poly.size(); i++)  // not shadow casters (:569-589)
+        P.bounds_shadow[P.sph.size() + P.tri.size() + i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};
     for (size_t i = 0; i < P.sph.size(); i++)
         if (P.sph[i].istransformed) {
             P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};  // never passes the main loop

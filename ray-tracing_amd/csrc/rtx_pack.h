@@ -97,6 +97,11 @@ struct PackedScene {
     std::vector<TriHot>      prim_hot;
     std::vector<rtx_triangle> tri;
     std::vector<rtx_light>   lights;
+    // polygons (raytracing.cpp:71-80, :289-325): raw records for the materials, vertices as float4 (x y z 0);
+    // the ray-independent part of intersectpolygon -- the negated normal, d = -(n . v0) (:309-312) and the area
+    // of the centroid fan (:320) -- sits in prim_hot: { n.xyz, d | totalArea, first_vertex, numvertices, 0 | 0.. }
+    std::vector<rtx_polygon> poly;
+    std::vector<float>       poly_verts;  // 4 floats per vertex
     // camera (raytracing.cpp:725-737)
     rtx_vec3 ncrossv, up, vpn, camera, orig, ambient;
     std::vector<float> imagex;           // per column, :753 evaluated in double, stored as float

@@ -53,13 +53,21 @@ class Light(C.Structure):
     _fields_ = [("point", Vec3), ("color", Vec3)]
 
 
+class Polygon(C.Structure):
+    _fields_ = [("numvertices", C.c_int32), ("first_vertex", C.c_int32), ("color", Vec3), ("speccoeff", Vec3),
+                ("diffcolor", Vec3), ("normal", Vec3), ("centerPoint", Vec3), ("reflectivity", C.c_float),
+                ("transparency", C.c_float), ("refractive_index", C.c_float), ("specexpo", C.c_float)]
+
+
 class SceneView(C.Structure):
     _fields_ = [("spheres", C.POINTER(Sphere)), ("nspheres", C.c_int32),
                 ("triangles", C.POINTER(Triangle)), ("ntriangles", C.c_int32),
                 ("planes", C.POINTER(Plane)), ("nplanes", C.c_int32),
                 ("lights", C.POINTER(Light)), ("nlights", C.c_int32),
                 ("camera", Vec3), ("vrp", Vec3), ("vpn", Vec3), ("up", Vec3), ("ambient", Vec3),
-                ("npolygons_ignored", C.c_int32)]
+                ("polygons", C.POINTER(Polygon)), ("npolygons", C.c_int32),
+                ("polygon_vertices", C.POINTER(Vec3)), ("npolygon_vertices", C.c_int32),
+                ("npolygons_dropped", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -91,7 +99,7 @@ class Stats(C.Structure):
 
 
 assert C.sizeof(Vec3) == 12 and C.sizeof(XMatrix) == 48 and C.sizeof(Sphere) == 120
-assert C.sizeof(Plane) == 40 and C.sizeof(Triangle) == 88 and C.sizeof(Light) == 24
+assert C.sizeof(Plane) == 40 and C.sizeof(Triangle) == 88 and C.sizeof(Light) == 24 and C.sizeof(Polygon) == 84
 
 # every symbol include/rtx.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -163,7 +171,7 @@ class Scene:
 
     @property
     def nprims(self):
-        return self.view.nspheres + self.view.ntriangles
+        return self.view.nspheres + self.view.ntriangles + self.view.npolygons
 
     def close(self):
         if self._p:

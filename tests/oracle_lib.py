@@ -79,7 +79,7 @@ def accept_matrix(scene, o, d, shadow=False):
     o = np.ascontiguousarray(o, dtype=np.float32)
     d = np.ascontiguousarray(d, dtype=np.float32)
     n = o.shape[0]
-    out = np.zeros((n, scene.nprims), dtype=np.uint8)
+    out = np.zeros((n, scene.view.nspheres + scene.view.ntriangles), dtype=np.uint8)  # spheres and triangles only
     lib().orc_accept_matrix(scene.ptr, n, o.ctypes.data, d.ctypes.data, int(shadow), out.ctypes.data)
     return out
 

@@ -30,13 +30,14 @@ def test_struct_layouts_match_reference(rt):
     h = rt.host
     # raytracing.cpp:15-68: vec 12, matrix 48, sphere 120, plane 40, triangle 88, light 24
     assert [C.sizeof(t) for t in (h.Vec3, h.XMatrix, h.Sphere, h.Plane, h.Triangle, h.Light)] == [12, 48, 120, 40, 88, 24]
+    assert C.sizeof(h.Polygon) == 84  # rt.cpp:71-80 with the vertex vector flattened
     assert h.Sphere.istransformed.offset == 12 and h.Sphere.radius.offset == 16 and h.Sphere.mat.offset == 72
     assert h.Triangle.color.offset == 36 and h.Triangle.reflectivity.offset == 72
 
 
 def test_abi_version_and_errors(rt):
     L = rt.lib()
-    assert L.rtx_abi_version() == 0x00010000
+    assert L.rtx_abi_version() == 0x00020000  # 2.0: rtx_polygon and the polygon fields of rtx_scene
     assert b"no HIP device" in L.rtx_strerror(-2)
     assert L.rtx_strerror(0) == b"ok"
 

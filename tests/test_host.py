@@ -46,14 +46,27 @@ def test_head_grammar_scene(rt):
     assert (v.nspheres, v.ntriangles, v.nlights, v.nplanes) == (2, 11, 2, 1)
 
 
-def test_polygon_records_are_consumed(rt, tmp_path):
+def test_polygon_records(rt, tmp_path):
+    """parseinput's polygon rules (rt.cpp:910-967): normal from the first three vertices, centroid, exact-equality
+    coplanarity check that DROPS the record, and the colour / diffuse / specular order of that record type."""
     p = tmp_path / "poly.txt"
-    p.write_text("3\ncamera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0 0 0\n"
-                 "polygon 4 0 0 -5 1 0 -5 1 1 -5 0 1 -5  1 1 1 .5 .5 .5 .1 .1 .1 0 0 1 5\n"
+    p.write_text("5\ncamera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0 0 0\n"
+                 "polygon 4 0 0 -5 1 0 -5 1 1 -5 0 1 -5  1 1 1 .5 .5 .5 .1 .1 .1 0.25 0 1 5\n"
+                 "polygon 4 0 0 -20  1 0 -20  1 1 -21  0 1 -20   1 0 0  1 0 0  1 1 1  0 0 1 5\n"
+                 "polygon 3 2 0 -7 2 2 -7 2 0 -9  0 1 0 0 0 1 1 0 0 0 0.5 1.5 9\n"
                  "sphere 0 0 -10 1  1 1 1  1 1 1  0 0 0  0 0 1 0 1\nlight 1 2 3 1 1 1\n")
     sc = rt.load_scene(str(p)); v = sc.view
-    assert (v.nspheres, v.nlights, v.npolygons_ignored) == (1, 1, 1)
+    assert (v.nspheres, v.nlights, v.npolygons, v.npolygons_dropped, v.npolygon_vertices) == (1, 1, 2, 1, 7)
     assert v.spheres[0].center.z == -10.0 and v.lights[0].point.y == 2.0
+    a, b = v.polygons[0], v.polygons[1]
+    assert (a.numvertices, a.first_vertex, b.numvertices, b.first_vertex) == (4, 0, 3, 4)   # the dropped one left no vertices
+    assert (a.normal.x, a.normal.y, abs(a.normal.z)) == (0.0, 0.0, 1.0)
+    assert (a.centerPoint.x, a.centerPoint.y, a.centerPoint.z) == (0.5, 0.5, -5.0)
+    assert (a.diffcolor.x, a.speccoeff.x, a.reflectivity, a.specexpo) == (0.5, np.float32(0.1), 0.25, 5.0)
+    assert (abs(b.normal.x), b.normal.y, b.normal.z) == (1.0, 0.0, 0.0)
+    assert (b.color.y, b.diffcolor.z, b.speccoeff.x, b.transparency, b.refractive_index) == (1.0, 1.0, 1.0, 0.5, 1.5)
+    assert v.polygon_vertices[6].z == -9.0
+    assert sc.nprims == 3
 
 
 def test_ppm_writer(rt, oracle, tmp_path):
