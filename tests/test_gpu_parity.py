@@ -131,3 +131,16 @@ def test_general_affine_scene_matches_oracle(rt, oracle, gpu, tmp_path):
     rgb_gpu, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
     rgb_cpu, _ = oracle.render_rgb8(sc, W, H, 4)
     assert_rgb8_parity(rgb_gpu, rgb_cpu, "general affine")
+
+
+@pytest.mark.parametrize("name", ["poly.txt", "quirks.txt", "affine.txt"])
+def test_packet_kernel_on_small_scenes(rt, gpu, name):
+    """800x450 > 2^18 rays sends generation 0 through the packet kernel (bitmap in file order) also for the
+    hand-written scenes: polygons (records that always pass), the sticky-flag and matrix quirks."""
+    sc = rt.load_scene(os.path.join(SCENES, name))
+    W, H = 800, 450
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 4))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
