@@ -144,3 +144,38 @@ def test_packet_kernel_on_small_scenes(rt, gpu, name):
     same = raw_equal_mask(a, b)
     assert same.all(), "%d pixels differ" % int((~same).sum())
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
+HEADER = "camera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0.1 0.2 0.3\n"
+EDGE_SCENES = {
+    "empty": "0\n" + HEADER,
+    "lights_only": "2\n" + HEADER + "light 1 2 3 1 1 1\nlight -1 2 3 1 1 1\n",
+    "no_lights": "2\n" + HEADER + "sphere 0 0 -10 3  1 1 1  1 1 1  .5 .5 .5  0.5 0 1 0 8\n"
+                 "triangle -5 -4 -8  5 -4 -8  0 -4 -30  1 1 1  1 1 1  .5 .5 .5  0.5 0 1 8\n",
+    "polygon_only": "2\n" + HEADER + "light 3 8 -2 1 1 1\n"
+                    "polygon 4 -6 -3 -6  6 -3 -6  6 -3 -40  -6 -3 -40  1 1 1  .7 .7 .7  .3 .3 .3  0.5 0 1 8\n",
+    "one_affine_sphere": "2\n" + HEADER + "light 3 8 -2 1 1 1\n"
+                         "sphere 0 0 -10 2  1 1 1  1 1 1  .5 .5 .5  0.5 0.5 1.3 1 8  2 0 0  0 1 0  0 0 0.5  0 0 0\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_SCENES))
+@pytest.mark.parametrize("size", [(1, 1), (67, 33), (800, 450)])
+def test_edge_scenes(rt, oracle, gpu, tmp_path, name, size):
+    """Empty and ragged inputs: no primitives, no lights, a single record of one kind; a 1 x 1 image, an odd
+    size (partial waves, thin kernels) and one above 2^18 rays (packet kernel)."""
+    p = tmp_path / (name + ".txt")
+    p.write_text(EDGE_SCENES[name])
+    sc = rt.load_scene(str(p))
+    W, H = size
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 4))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    assert raw_equal_mask(a, b).all()
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    if W * H <= 67 * 33:
+        raw_cpu, cnt = oracle.render_f32(sc, W, H, 4)
+        assert sa.rays_primary + sa.rays_secondary == cnt.trace_calls and sa.rays_shadow == cnt.shadow_rays
+        assert raw_equal_mask(a, raw_cpu).mean() >= 0.999
+        rgb_gpu, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
+        rgb_cpu, _ = oracle.render_rgb8(sc, W, H, 4)
+        assert_rgb8_parity(rgb_gpu, rgb_cpu, name)
