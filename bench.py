@@ -213,6 +213,19 @@ def main():
                         flops_per_frame=flops, tests_per_frame=[float(k) for k in kinds])
             cctx.close()
         out["roofline"] = roof
+    # ---- end to end at the C-ABI: untimed extras, N = 1 only ----
+    if rank == 0 and world == 1:
+        import numpy as np
+        t0 = time.perf_counter()
+        ctx.render(stream, None)
+        img = ctx.read_rgb8()                      # waits for the frame, copies 3 B / pixel to the host
+        t1 = time.perf_counter()
+        rgb, _ = rt.render_rgb8(scene, rt.Params.make(W, H, md, device=local_rank))  # create + upload + render + D2H + destroy
+        t2 = time.perf_counter()
+        assert np.array_equal(img, rgb)
+        out["end_to_end"] = {"resident_render_plus_d2h_ms": (t1 - t0) * 1e3, "one_shot_rtx_render_rgb8_ms": (t2 - t1) * 1e3,
+                             "note": "value above is the resident render with the frame left in HBM; these two add the "
+                                     "24.9 MB device-to-host copy, and context creation (scene upload, queue allocation) + teardown"}
     if world > 1:
         dist.barrier()
     if rank == 0:
