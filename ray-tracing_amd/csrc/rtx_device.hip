@@ -5,10 +5,14 @@
 //
 //   raygen                       level-0 rays, one thread per pixel            (:753-759)
 //   for level k = 0 .. max_depth
-//     closest_hit(k)             brute force over all spheres, then triangles   (:382-419)
+//     closest_hit(k)             spheres, triangles, polygons in file order     (:382-434)
+//                                level 0: packets of 64 coherent rays against a cluster hierarchy;
+//                                level >= 1: every ray walks the hierarchy itself; both reproduce the
+//                                reference's sequential scan exactly
 //     hit_setup(k)               hit point / normal, spawn reflect + refract
-//                                rays into level k+1 (wave-ballot compaction)   (:436-526)
-//     shadow_any(k)              one any-hit ray per (hit, light)               (:560-589)
+//                                rays into level k+1 (queue slots per workgroup) (:436-526)
+//     shadow_any(k)              one any-hit ray per (hit, light), sorted by light and direction,
+//                                on a side stream                               (:560-589)
 //   for level k = max_depth .. 0
 //     unwind(k)                  children first, then lights in file order,
 //                                then ambient: the reference's add order        (:446-646)
@@ -67,13 +71,12 @@ struct SceneDev {
     const rtx_light* lights;      // [nl]
     F3 ambient;
     const float4* bounds;         // [ns+nt] filter records { c, -R^2 } (rtx_bounds.cpp)
-    const float4* bounds_shadow;  // [ns+nt] the same for the shadow-ray call pattern (affine spheres never pass)
     const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
     int naff;
     F3 box_lo, box_inv;           // scene box for ray binning: cell = (o - box_lo) * box_inv, 16 cells per axis
     unsigned long long* pstat;    // [8] packet statistics: closest {waves, waves ok, batches, survivors}, shadow {same}
-    const float4* sbounds;        // [nsb] shadow-ordered filter records (no affine spheres), big occluders first
-    const int* sorder;            // [nsb] primitive index of each
+    const float4* sbounds;        // [nsb] filter records of the shadow casters except affine spheres (transposed scan of
+    const int* sorder;            // [nsb]  unpacketable rays), and the primitive index of each
     int nsb;
     float guard;                  // |origin component| beyond this: the ray bypasses the filter
     // two-level packet test (rtx_pack.h, ClusterSet): cluster spheres, their 64 members, member -> primitive
@@ -398,7 +401,6 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 // with a = |w.C|, h^2 = |C|^2 - a^2, squared, every rounding pushed to the passing side.  Waves with an
 // abnormal lane, or a cone wider than ~70 degrees, do not use it (they take the grouped loop).
 // ------------------------------------------------------------------------------------------------
-constexpr int kPacketDense = 20;  // more survivors than this in a batch of 64: use the grouped loop for the batch
 struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; float c0; bool ok; };  // c0 = cos(theta), rounded down, before the widening by E
 
 __device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
@@ -497,8 +499,6 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     const bool use = live && !abn;
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
     F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
-    asm volatile("" : "+v"(accinit));
     HitAcc h;
     h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
     const Packet P = make_packet(o, nd, live, abn);
@@ -808,7 +808,6 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
 // `transformed` flag (:396-399) is set iff some slice's last affine-sphere record beats the minimum
 // of the slices before it.
 constexpr int kThinRays = 1 << 18;
-constexpr int kThinShadow = 1 << 14;  // shadow rays are light-binned packets at any population above this
 constexpr int kThinTile = kTile / 4;
 
 __device__ __forceinline__ int stage_thin(float4* mt, const float4* bounds, int t0, int end, int lane)
@@ -929,11 +928,9 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
 
 // Shadow rays (raytracing.cpp:560-589) are any-hit: which primitive blocks the light first does not
 // matter, only whether one does.  So they are not traced in file order in one long loop.  They are
-// materialised once per generation (k_shadow_gen), then pushed through the primitive list in CHUNKS,
-// largest expected occluders first (SceneDev::sbounds); after every chunk the rays still unblocked
-// are compacted into the next queue with a wave64 ballot (k_shadow_pass), so waves stay full while
-// the ray population collapses (96 % of the benchmark scene's shadow rays are blocked).  Affine
-// spheres come last, through their own filter (k_shadow_aff).
+// materialised once per generation into a queue sorted by (light, direction cell) (k_shadow_bin, k_scan_*,
+// k_shadow_scatter) and traced by k_shadow_pass as packets with their apex at the light: plain spheres
+// and triangles through the shadow cluster hierarchy, affine spheres through a strip test of their own.
 struct ShadowQ { float *ox, *oy, *oz, *dx, *dy, *dz; int* id; };
 
 // Light-space binning.  Every shadow ray's line passes through its light, so rays towards one light
@@ -1166,7 +1163,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     const int i = base + threadIdx.x;
     const int ii = (i < n) ? i : 0;
     const int id = Qi.id[ii];
-    const bool live = (i < n) && id >= 0;  // id < 0: padding slot of the previous pass's compaction
+    const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
     F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
     F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
     F3 nld = normalized(ld);
@@ -1174,8 +1171,6 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     const bool use = live && !abn;
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
     F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
-    asm volatile("" : "+v"(accinit));
     bool done = !live;
     int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0, pk_aff = 0;
     auto bcast4 = [](float4 v, int u) {
@@ -1681,10 +1676,8 @@ struct rtx_context {
     std::vector<hipEvent_t> ev_fork;
     int* r_hist = nullptr; int* r_offs = nullptr; int* r_rank = nullptr; int* r_bsum = nullptr; int* r_braw = nullptr;
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
-    std::vector<int> sched;                 // chunk boundaries of the shadow-ordered primitive list
-    int* d_scnt = nullptr;                  // [nchunks*levels*(npass+2)] live shadow rays entering each pass
-    int scnt_stride = 0, nframe_chunks = 0;
-    std::vector<int> sb_kind;               // kind (0 sphere, 2 triangle) of each shadow-ordered primitive
+    int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
+    int nframe_chunks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
@@ -1807,10 +1800,6 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&bnd, P.bounds.size()))) return rc;
         if (!P.bounds.empty()) HIPCHK(hipMemcpy(bnd, P.bounds.data(), P.bounds.size() * sizeof(float4), hipMemcpyHostToDevice));
         c->S.bounds = bnd;
-        float4* bnds = nullptr;
-        if ((rc = c->dalloc(&bnds, P.bounds_shadow.size()))) return rc;
-        if (!P.bounds_shadow.empty()) HIPCHK(hipMemcpy(bnds, P.bounds_shadow.data(), P.bounds_shadow.size() * sizeof(float4), hipMemcpyHostToDevice));
-        c->S.bounds_shadow = bnds;
         static_assert(sizeof(AffineShadowRec) == 4 * sizeof(float4), "affine shadow record is four float4");
         float4* aff = nullptr;
         if ((rc = c->dalloc(&aff, P.aff_shadow.size() * 4))) return rc;
@@ -1822,12 +1811,6 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (!P.sbounds.empty()) HIPCHK(hipMemcpy(sb, P.sbounds.data(), P.sbounds.size() * sizeof(float4), hipMemcpyHostToDevice));
         if ((rc = c->upload(&so, P.sorder))) return rc;
         c->S.sbounds = sb; c->S.sorder = so; c->S.nsb = (int)P.sbounds.size();
-        for (int32_t k : P.sorder) c->sb_kind.push_back(k < (int)P.sph.size() ? 0 : 2);
-        // shadow pass schedule: with light-space binning the packet test makes one pass over the whole
-        // list cheaper than several passes with compaction in between (measured: the first pass keeps
-        // 0.23 primitives per batch of 64; later passes, fed by compacted queues, kept ~10)
-        c->sched.push_back(0);
-        if (c->S.nsb > 0) c->sched.push_back(c->S.nsb);
         c->S.guard = P.guard;
         {
             auto up4 = [&](const std::vector<BoundSphere>& v, const float4** dst) -> int {
@@ -1956,8 +1939,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&c->d_perm, (size_t)c->L[levels - 1].cap))) return rc;
         if ((rc = c->dalloc(&c->d_dummy, (size_t)1))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
-        c->scnt_stride = (int)c->sched.size() + 1;
-        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride))) return rc;
+        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels))) return rc;
     }
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -1969,7 +1951,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     for (auto& e : c->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (params->flags & RTX_F_TIME_KERNELS) {
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
-        c->kev.resize((size_t)nchunks * levels * 2 * (1 + c->sched.size()));
+        c->kev.resize((size_t)nchunks * levels * 2 * 2);  // (start, stop) x (closest, shadow) per generation and chunk
         for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
     }
     return RTX_OK;
@@ -1988,7 +1970,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
     HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 8, st));
     HIPCHK(hipMemsetAsync(c->d_pstat, 0, sizeof(unsigned long long) * 8, st));
-    HIPCHK(hipMemsetAsync(c->d_scnt, 0, sizeof(int) * (size_t)std::max(c->nframe_chunks, 1) * levels * c->scnt_stride, st));
+    HIPCHK(hipMemsetAsync(c->d_scnt, 0, sizeof(int) * (size_t)std::max(c->nframe_chunks, 1) * levels, st));
     const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
     const bool exact_only = (c->params.flags & RTX_F_EXACT_ONLY) != 0;
     const bool timek = !c->kev.empty();
@@ -2038,13 +2020,13 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 else hipLaunchKernelGGL(k_shadow<false>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             } else if (c->S.nl > 0) {
-                // materialise the shadow rays, then chunked any-hit passes with compaction in between -- on the side stream
+                // materialise and sort the shadow rays, then one any-hit pass -- on a side stream
                 rtx_context::ShadowLane& sl = c->side[k % rtx_context::kSide];
                 hipStream_t ss = sl.stream;
                 HIPCHK(hipEventRecord(c->ev_fork[k], st));
                 HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
                 sl.used = true;
-                int* sc = c->d_scnt + ((size_t)nchunks * levels + k) * c->scnt_stride;
+                int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
                 HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
                 hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
                 {

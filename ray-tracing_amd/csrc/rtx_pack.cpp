@@ -288,14 +288,8 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
     for (size_t i = 0; i < P.tri.size(); i++) P.bounds.push_back(bound_sphere_triangle(P.tri[i], guard));
     // polygons are not bounded yet: every ray takes their exact test (records that always pass)
     for (size_t i = 0; i < P.poly.size(); i++) P.bounds.push_back({0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()});
-    P.bounds_shadow = P.bounds;
-    for (size_t i = 0; i < P.poly.size(); i++)  // not shadow casters (:569-589)
-        P.bounds_shadow[P.sph.size() + P.tri.size() + i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};
     for (size_t i = 0; i < P.sph.size(); i++)
-        if (P.sph[i].istransformed) {
-            P.bounds_shadow[i] = {0.0f, 0.0f, 0.0f, std::numeric_limits<float>::infinity()};  // never passes the main loop
-            P.aff_shadow.push_back(affine_shadow_record(P.sph[i], P.sph_im[i], (int)i));
-        }
+        if (P.sph[i].istransformed) P.aff_shadow.push_back(affine_shadow_record(P.sph[i], P.sph_im[i], (int)i));
 
     {   // shadow order: mean projected area, descending (sphere pi r^2, triangle area / 2); primitives the
         // filter cannot bound (always pass: an exact test every time) go last

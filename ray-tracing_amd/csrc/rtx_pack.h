@@ -76,14 +76,12 @@ struct PackedScene {
     ClusterSet sc;                            // shadow clusters over `sbounds`, one segment
     std::vector<AffineShadowRec> aff_shadow;  // one per affine sphere, file order
     // Shadow rays are any-hit: the order primitives are tried in cannot change the result, only how
-    // soon a blocked ray stops.  sbounds = filter records of every primitive except affine spheres,
-    // largest expected occluder first; sorder[i] = primitive index (sphere i | ns + triangle i).
+    // soon a blocked ray stops.  sbounds = filter records of the shadow casters (spheres and triangles; polygons
+    // cast none, :569-589) except affine spheres (aff_shadow: the reference transforms only the direction there,
+    // :571-576), largest expected occluder first; sorder[i] = primitive index (sphere i | ns + triangle i).
     std::vector<BoundSphere> sbounds;
     std::vector<int32_t>     sorder;
     std::vector<BoundSphere> bounds;     // [nspheres + ntriangles], closest-hit call pattern
-    std::vector<BoundSphere> bounds_shadow; // same for shadow rays: affine spheres always pass there, because
-                                         // the reference transforms only the direction, not the origin (:571-576);
-                                         // here they NEVER pass, and are handled through aff_shadow instead
     float guard = 1.0f;                  // rays with an origin component beyond this bypass the filter
     std::vector<SphHot>      sph_hot;
     std::vector<int32_t>     sph_xf;     // istransformed (:34)
