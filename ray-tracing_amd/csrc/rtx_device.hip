@@ -161,21 +161,24 @@ __device__ __forceinline__ int wave_alloc(bool want, int* counter)
     return want ? base + prefix : -1;
 }
 
-// The same for a whole 256-thread workgroup: slots keep the threads' order and the shared counter
-// takes one atomic per workgroup (same-address atomics cost ~5-12 ns each on this chip; a 4K frame's
-// set-up kernel issues 130,000 wave-level ones per queue otherwise).
+// The same for a whole workgroup of up to 1024 threads: slots keep the threads' order and the shared counter
+// takes ONE atomic per workgroup.  Same-address atomics are serialised at ~10 ns each on this chip: the set-up
+// kernel of a 4K frame spent 0.33 ms per queue on 32,400 of them with 256-thread workgroups, which is why it
+// runs 1024-thread workgroups at generation 0.  sh: blockDim.x / 64 + 1 ints.
+constexpr int kSetupBlock = 1024;
 __device__ __forceinline__ int block_alloc(bool want, int* counter, int* sh)
 {
     unsigned long long m = __ballot(want);
     int lp = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    const int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) sh[w] = __popcll(m);
     __syncthreads();
     int woff = 0, tot = 0;
-    for (int k = 0; k < kBlock / 64; k++) { if (k < w) woff += sh[k]; tot += sh[k]; }
-    if (threadIdx.x == 0) sh[4] = tot ? atomicAdd(counter, tot) : 0;
+    for (int k = 0; k < nw; k++) { if (k < w) woff += sh[k]; tot += sh[k]; }
     __syncthreads();
-    const int base = sh[4];
+    if (threadIdx.x == 0) sh[nw] = tot ? atomicAdd(counter, tot) : 0;
+    __syncthreads();
+    const int base = sh[nw];
     __syncthreads();
     return want ? base + woff + lp : -1;
 }
@@ -1381,17 +1384,18 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
 // ------------------------------------------------------------------------------------------------
 // K3 hit set-up and spawn (raytracing.cpp:436-526)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelDev N, const int* nrays,
-                                                  int* nnodes, int* nnext, int spawn)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDev N, const int* nrays,
+                                                 int* nnodes, int* nnext, int spawn)
 {
-    int i = blockIdx.x * kBlock + threadIdx.x;
+    int i = blockIdx.x * BLOCK + threadIdx.x;
     bool live = i < *nrays;
     int pw = live ? L.prim[i] : -1;
     bool hit = pw >= 0;
     if (live && !hit) {  // :436-438: background, no ambient
         L.val[3 * i + 0] = 0.4f; L.val[3 * i + 1] = 0.4f; L.val[3 * i + 2] = 0.4f;
     }
-    __shared__ int sh_alloc[8];
+    __shared__ int sh_alloc[2 * (BLOCK / 64) + 1];
     int node = block_alloc(hit, nnodes, sh_alloc);
     bool want_refl = false, want_refr = false;
     F3 o = f3(0, 0, 0), d = o, normal = o, ip = o, rd = o;
@@ -1459,8 +1463,29 @@ __global__ __launch_bounds__(kBlock) void k_setup(SceneDev S, LevelDev L, LevelD
         if (hit) { L.n_crefl[node] = -1; L.n_crefr[node] = -1; }
         return;
     }
-    int crefl = block_alloc(want_refl, nnext, sh_alloc);
-    int crefr = block_alloc(want_refr, nnext, sh_alloc);
+    // both kinds of child from ONE allocation per workgroup: reflection rays take the first slots of the
+    // workgroup's run, refraction rays the rest (two barriers instead of six)
+    int crefl = -1, crefr = -1;
+    {
+        const unsigned long long m1 = __ballot(want_refl), m2 = __ballot(want_refr);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        constexpr int nw = BLOCK / 64;
+        const int p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
+        const int p2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
+        if (lane == 0) { sh_alloc[w] = __popcll(m1); sh_alloc[nw + w] = __popcll(m2); }  // free: block_alloc ended with a barrier
+        __syncthreads();
+        int off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
+        for (int k = 0; k < nw; k++) {
+            if (k < w) { off1 += sh_alloc[k]; off2 += sh_alloc[nw + k]; }
+            tot1 += sh_alloc[k]; tot2 += sh_alloc[nw + k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh_alloc[2 * nw] = (tot1 + tot2) ? atomicAdd(nnext, tot1 + tot2) : 0;
+        __syncthreads();
+        const int base = sh_alloc[2 * nw];
+        if (want_refl) crefl = base + off1 + p1;
+        if (want_refr) crefr = base + tot1 + off2 + p2;
+    }
     if (hit) { L.n_crefl[node] = crefl; L.n_crefr[node] = crefr; }
     if (want_refl) {  // :464-468
         F3 r = f3(rd.x + 2.0f * fratio * normal.x, rd.y + 2.0f * fratio * normal.y, rd.z + 2.0f * fratio * normal.z);
@@ -2012,7 +2037,12 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
-            hipLaunchKernelGGL(k_setup, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
+            // generation 0 runs alone and every workgroup allocates: 1024-thread workgroups quarter its same-address
+            // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits
+            // for a whole CU to drain
+            if (k == 0) hipLaunchKernelGGL(k_setup<kSetupBlock>, dim3((unsigned)((live_cap + kSetupBlock - 1) / kSetupBlock)), dim3(kSetupBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
+                               spawn ? rays + k + 1 : rays + k, spawn);
+            else hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
                                spawn ? rays + k + 1 : rays + k, spawn);
             if (c->S.nl > 0 && (count || exact_only)) {
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
