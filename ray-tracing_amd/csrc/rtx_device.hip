@@ -121,6 +121,29 @@ __device__ __forceinline__ TriRec load_tri(const float4* hot, int i)
     return T;
 }
 
+// The 80-byte hot record of one primitive in registers (SceneDev::phot).  The lanes that need records
+// fetch them with five independent loads -- one memory round trip for up to 64 primitives -- and a
+// wave-uniform exact test then reads its record by v_readlane instead of a chain of scalar loads.
+struct PrimRec { float4 q0, q1, q2, q3, q4; };
+
+__device__ __forceinline__ PrimRec load_prim(const float4* phot, int k)
+{
+    const float4* p = phot + (size_t)k * 5;
+    PrimRec r;
+    r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2]; r.q3 = p[3]; r.q4 = p[4];
+    return r;
+}
+
+__device__ __forceinline__ float4 bcast4(float4 v, int u)
+{
+    float4 r;
+    r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), u));
+    r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), u));
+    r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.z), u));
+    r.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.w), u));
+    return r;
+}
+
 // raytracing.cpp:303-325 with the ray-independent head precomputed (rtx_pack.cpp): q0 = { n, d } with n the
 // stored normal NEGATED (always: :308 is `true` once it compiles; :305 compares a function
 // with 0 and never fires), q1 = { area of the centroid fan, first vertex, vertex count, - }.
@@ -388,6 +411,48 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 }
 
 
+// exact_closest for a wave-uniform primitive k whose hot record sits in lane u's registers
+__device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, const PrimRec& pr, int u, bool pass, F3 o, F3 d, F3 nd, HitAcc& h)
+{
+    const float4 q0 = bcast4(pr.q0, u);
+    if (k < S.ns) {
+        const float4 q4 = bcast4(pr.q4, u);
+        const bool xf = q4.x != 0.0f;
+        F3 to = o, td = nd;
+        if (xf) {  // wave-uniform
+            const float4 q1 = bcast4(pr.q1, u), q2 = bcast4(pr.q2, u), q3 = bcast4(pr.q3, u);
+            rtx_xmatrix im;
+            im.a.x = q1.x; im.a.y = q1.y; im.a.z = q1.z; im.b.x = q1.w;
+            im.b.y = q2.x; im.b.z = q2.y; im.c.x = q2.z; im.c.y = q2.w;
+            im.c.z = q3.x; im.d.x = q3.y; im.d.y = q3.z; im.d.z = q3.w;
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (pass && sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) { h.tflag = kTFlag; h.txf = t; } }
+        }
+    } else if (k < S.ns + S.nt) {
+        const float4 q1 = bcast4(pr.q1, u), q2 = bcast4(pr.q2, u), q3 = bcast4(pr.q3, u), q4 = bcast4(pr.q4, u);
+        TriRec T;
+        T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
+        T.vx = q1.x; T.vy = q1.y; T.vz = q1.z; T.area = q1.w;
+        T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
+        T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
+        T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
+        float t, vd;
+        if (pass && triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    } else {
+        const float4 q1 = bcast4(pr.q1, u);
+        float t;
+        if (pass && polygon_test(o, d, q0, q1, S.poly_verts, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Packet test.  A wave's 64 rays are bounded by a sphere around their origins (co, rho) and a cone
 // around their directions (axis w, half-angle theta).  Each LANE then tests a DIFFERENT primitive's
@@ -487,6 +552,7 @@ __device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
     return rhs * rhs * 1.00001f - h2 * cosE2;
 }
 
+template <bool PREFETCH>
 __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
 {
     const int lane = threadIdx.x & 63;
@@ -509,7 +575,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     const int nprim = S.ns + S.nt + S.np;
     // this wave's bitmap of candidate primitives of the current segment (wave-private LDS: the wave's
     // DS operations execute in issue order, the fences only pin the compiler's ordering)
-    volatile unsigned* bm = reinterpret_cast<volatile unsigned*>(tile) + (threadIdx.x >> 6) * (kSegPrims / 32);
+    volatile unsigned* bm = reinterpret_cast<volatile unsigned*>(tile) + (threadIdx.x >> 6) * (kSegPrims / 32 + 512);  // + 1024-entry candidate list
     for (int seg = 0; seg < S.cnseg; seg++) {
         const int p0 = seg * kSegPrims;
         const int pn = min(kSegPrims, nprim - p0);
@@ -537,7 +603,56 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
             for (int j = lane; j < words; j += 64) bm[j] = (j * 32 + 32 <= pn) ? 0xFFFFFFFFu : ((1u << (pn & 31)) - 1u);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // walk the bitmap in index order: file order, as the reference's loops (:385-418)
+        if constexpr (PREFETCH) {
+        // Walk the bitmap in index order: file order, as the reference's loops (:385-418).
+        // Few waves per SIMD (frames below ~4 M rays): a wave's serial chain of dependent loads IS the run time.
+        // The set bits of 32 words are first written out as a list (wave-level prefix sum of the popcounts keeps
+        // the order), then 64 candidates at a time fetch their filter record and hot record with independent
+        // loads -- one memory round trip for the lot -- and the ordered loop reads them from registers.
+        volatile unsigned short* list = reinterpret_cast<volatile unsigned short*>(const_cast<unsigned*>(bm) + kSegPrims / 32);
+        for (int w0 = 0; w0 < words; w0 += 32) {
+            const unsigned wv = (lane < 32 && w0 + lane < words) ? bm[w0 + lane] : 0u;
+            const int cnt = __popc(wv);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            const int tot = __shfl(incl, 63);
+            if (tot == 0) continue;  // wave-uniform
+            {
+                unsigned bits = wv;
+                int pos = incl - cnt;
+                while (bits) {
+                    const int bpos = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    list[pos++] = (unsigned short)(lane * 32 + bpos);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int c0 = 0; c0 < tot; c0 += 64) {
+                const int m = min(64, tot - c0);
+                int k = 0;
+                float4 br = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                PrimRec pr;
+                pr.q0 = pr.q1 = pr.q2 = pr.q3 = pr.q4 = br;
+                if (lane < m) {
+                    k = p0 + (w0 << 5) + (int)list[c0 + lane];
+                    br = S.bounds[k];
+                    pr = load_prim(S.phot, k);
+                }
+                for (int u = 0; u < m; u++) {
+                    const float4 b = bcast4(br, u);
+                    const bool pass = live && (abn || !(filt(fo, fd, b) < 0.0f));
+                    if (__any(pass)) exact_closest_bcast(S, __builtin_amdgcn_readlane(k, u), pr, u, pass, o, d, nd, h);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        } else {
+        // Many waves per SIMD (a 4K frame): latency hides itself and the plain ordered loop costs fewer
+        // instructions -- one scalar-loaded filter record and, on a pass, one exact test per set bit.
         for (int w0 = 0; w0 < words; w0 += 64) {
             const unsigned wv = (w0 + lane < words) ? bm[w0 + lane] : 0u;
             unsigned long long nz = __ballot(wv != 0u);
@@ -553,6 +668,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                     if (live && (abn || !(filt(fo, fd, br) < 0.0f))) exact_closest(S, k, o, d, nd, h);
                 }
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -880,14 +996,16 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     }
 }
 
+template <bool PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
-    __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps
+    __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps (2 KiB) and candidate lists (2 KiB)
+    static_assert((kSegPrims / 32 + 512) * 4 * (kBlock / 64) <= kTile * 16, "bitmaps and lists fit");
     const int n = *nrays;
     if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;  // block-uniform
-        closest_packet(S, L, n, base, tile, perm);
+        closest_packet<PREFETCH>(S, L, n, base, tile, perm);
     } else {
         if (blockIdx.x * 64 >= n) return;
         closest_thin(S, L, n, tile);
@@ -899,6 +1017,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 // generation has fewer waves than the chip has SIMDs; its run time is one wave's serial walk, now a
 // third as long.
 constexpr int kSplitClosest = 1 << 17;
+constexpr size_t kPrefetchRays = (size_t)1 << 22;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
@@ -2035,7 +2154,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
-            else hipLaunchKernelGGL(k_closest_f, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            else if (live_cap < kPrefetchRays) hipLaunchKernelGGL(k_closest_f<true>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            else hipLaunchKernelGGL(k_closest_f<false>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
             // generation 0 runs alone and every workgroup allocates: 1024-thread workgroups quarter its same-address
             // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits

@@ -52,7 +52,7 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
 // per segment of kSegPrims consecutive primitives and only mark bits in a per-wave bitmap that is then
 // walked in index order; shadow rays are any-hit and test members as they come.
 constexpr int kClusterSize = 64;
-constexpr int kSegPrims = 1 << 15;
+constexpr int kSegPrims = 1 << 14;
 struct ClusterSet {
     std::vector<BoundSphere> cl;        // [ncl]
     std::vector<BoundSphere> mem;       // [ncl * 64], padding: idx = -1

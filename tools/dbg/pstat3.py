@@ -4,8 +4,11 @@ import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
-ctx = rt.Context(sc, rt.Params.make(3840, 2160, 0, flags=rt.host.F_PACKET_STATS))
-ctx.render(); st = ctx.stats()
-ps = list(st.packet_stats)
-print("blocks", ps[4], "batches/block", ps[6] / ps[4], "main survivors/block", (ps[7] & 0xffffffff) / ps[4], "affine survivors/block", (ps[7] >> 32) / ps[4])
-ctx.close()
+prev = None
+for md in (0, 1):
+    ctx = rt.Context(sc, rt.Params.make(3840, 2160, md, flags=rt.host.F_PACKET_STATS))
+    ctx.render(); st = ctx.stats()
+    ps = list(st.packet_stats)
+    if prev: print("L1 rays", st.rays_level[1], "waves", (st.rays_level[1] + 63) // 64, "packet waves", ps[0] - prev[0], "batches/packet wave", (ps[2] - prev[2]) / max(ps[0] - prev[0], 1), "kept/packet wave", (ps[3] - prev[3]) / max(ps[0] - prev[0], 1))
+    prev = ps
+    ctx.close()
