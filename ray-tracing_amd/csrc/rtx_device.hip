@@ -589,14 +589,35 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                 unsigned long long cm = __ballot(c < c1 && packet_test(P, S.ccl[min(c, c1 - 1)]));
                 pk_batches++;
                 while (cm) {
-                    const int j = __ffsll((long long)cm) - 1;
-                    cm &= cm - 1;
-                    const size_t m = (size_t)(cb + j) * 64 + lane;
-                    const float4 mb = S.cmem[m];
-                    const int k = S.cidx[m];
-                    const bool pass = k >= 0 && packet_test(P, mb);
-                    if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
-                    pk_batches++; pk_surv += __popcll(__ballot(pass));
+                    if constexpr (PREFETCH) {
+                        // four clusters' members in flight at a time: one memory round trip per four
+                        int jj[4];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) { jj[a] = cm ? (__ffsll((long long)cm) - 1) : -1; cm &= cm - 1; }
+                        float4 mb[4];
+                        int kk[4];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) {
+                            const size_t m = (size_t)(cb + max(jj[a], 0)) * 64 + lane;
+                            mb[a] = S.cmem[m];
+                            kk[a] = S.cidx[m];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; a++) {
+                            const bool pass = jj[a] >= 0 && kk[a] >= 0 && packet_test(P, mb[a]);
+                            if (pass) atomicOr(const_cast<unsigned*>(bm) + ((kk[a] - p0) >> 5), 1u << ((kk[a] - p0) & 31));
+                            if (jj[a] >= 0) { pk_batches++; pk_surv += __popcll(__ballot(pass)); }
+                        }
+                    } else {
+                        const int j = __ffsll((long long)cm) - 1;
+                        cm &= cm - 1;
+                        const size_t m = (size_t)(cb + j) * 64 + lane;
+                        const float4 mb = S.cmem[m];
+                        const int k = S.cidx[m];
+                        const bool pass = k >= 0 && packet_test(P, mb);
+                        if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
+                        pk_batches++; pk_surv += __popcll(__ballot(pass));
+                    }
                 }
             }
         } else {
