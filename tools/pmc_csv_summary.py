@@ -13,6 +13,7 @@ for path in sys.argv[1:]:
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 names = sorted({c for d in agg.values() for c in d if c not in ("dispatches", "vgpr", "lds")})
 w = csv.writer(sys.stdout)
-w.writerow(["kernel", "vgpr", "lds_bytes"] + names)
+w.writerow(["kernel", "vgpr", "lds_bytes", "dispatches_per_pass"] + names)
 for k, d in agg.items():
-    w.writerow([k, d["vgpr"], d["lds"]] + ["%.6g" % d.get(c, 0.0) for c in names])
+    npass = len({p for p, _ in d["dispatches"]})
+    w.writerow([k, d["vgpr"], d["lds"], len(d["dispatches"]) // max(npass, 1)] + ["%.6g" % d.get(c, 0.0) for c in names])
