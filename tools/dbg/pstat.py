@@ -1,5 +1,5 @@
 import sys, os, tempfile
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
