@@ -1,0 +1,752 @@
+// rtx_closest.hip.h -- closest hit: bounding-sphere filter, packet test, k_closest_f (coherent waves), k_closest_lanes (per-ray traversal), secondary-ray binning
+// Part of the one translation unit rtx_device.hip (device code, namespace rtx); not a stand-alone header.
+#ifndef RTX_CLOSEST_HIP_H_
+#define RTX_CLOSEST_HIP_H_
+
+namespace rtx {
+
+// ------------------------------------------------------------------------------------------------
+// Filtered intersection kernels (the default hot path).
+//
+// Every (ray, primitive) pair first takes an 11-instruction FMA test of the ray's line against a
+// conservative bounding sphere of the primitive (rtx_bounds.cpp proves it never rejects a pair
+// the reference's test accepts); only survivors run the exact contraction-free test above.
+// Bounding-sphere records are staged through LDS in tiles of kTile primitives and read back
+// with broadcast ds_read_b128 (all lanes, same address): primitive operands then sit in VGPRs,
+// which on gfx950 issue at twice the rate of SGPR / constant-bus operands (tools/ubench_valu2).
+// The sign bits of F over a group of kGroup primitives are AND-ed (v_and_b32, full rate) and
+// tested once per group, instead of one half-rate v_cmp per primitive.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTile = 1024;   // primitives per LDS tile (16 KiB)
+constexpr int kGroup = 8;     // primitives per sign-AND group
+
+__device__ __forceinline__ float filt(F3 fo, F3 fd, float4 b)
+{
+    float X = fo.x - b.x, Y = fo.y - b.y, Z = fo.z - b.z;
+    float bh = fd.z * Z;
+    bh = __builtin_fmaf(fd.y, Y, bh);
+    bh = __builtin_fmaf(fd.x, X, bh);
+    float cc = __builtin_fmaf(Z, Z, b.w);
+    cc = __builtin_fmaf(Y, Y, cc);
+    cc = __builtin_fmaf(X, X, cc);
+    return __builtin_fmaf(bh, bh, -cc);
+}
+
+__device__ __forceinline__ bool finite3(F3 v)
+{
+    return (fabsf(v.x) <= 3.0e38f) && (fabsf(v.y) <= 3.0e38f) && (fabsf(v.z) <= 3.0e38f);
+}
+__device__ __forceinline__ bool tiny_comp(float c) { return c != 0.0f && fabsf(c) < 1e-10f; }
+
+// A ray the filter's error analysis does not cover: it skips the filter and takes the exact test
+// against every primitive (rtx_bounds.cpp, "abnormal" lanes).
+__device__ __forceinline__ bool ray_abnormal(F3 o, F3 d, F3 nd, float guard)
+{
+    bool ok = finite3(o) && finite3(d) && finite3(nd);
+    float n2 = nd.x * nd.x + nd.y * nd.y + nd.z * nd.z;
+    bool dir = (fabsf(n2 - 1.0f) <= 1e-3f);
+    dir = dir && (fabsf(d.x - nd.x) <= 1e-5f) && (fabsf(d.y - nd.y) <= 1e-5f) && (fabsf(d.z - nd.z) <= 1e-5f);
+    dir = dir && !(tiny_comp(d.x) || tiny_comp(d.y) || tiny_comp(d.z) || tiny_comp(nd.x) || tiny_comp(nd.y) || tiny_comp(nd.z));
+    // A direction of exactly (0,0,0) -- what the reference's normalize (:116-125) leaves behind when a
+    // singular sphere matrix has flattened the incoming ray -- is a POINT: with fd = 0 the filter
+    // reads R^2 - |X|^2 >= 0, "the origin lies inside the bounding sphere", which is what the exact
+    // tests need too (sphere: b = 0, disc = -4c >= 0; triangle: vd == 0 rejects) -- rtx_bounds.cpp.
+    dir = dir || (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);
+    ok = ok && dir;
+    ok = ok && (fabsf(o.x) <= guard) && (fabsf(o.y) <= guard) && (fabsf(o.z) <= guard);
+    return !ok;
+}
+
+constexpr float kDirScale = 1.0f + 1.0f / 262144.0f;  // (1 + 2^-18), see rtx_bounds.cpp
+
+// Block-cooperative staging of one tile of filter records; the tail of the last group is padded
+// with records no ray can pass (R^2 = -inf).
+__device__ __forceinline__ int stage_tile(float4* tile, const float4* bounds, int t0, int nprim)
+{
+    int cnt = min(kTile, nprim - t0);
+    for (int j = threadIdx.x; j < cnt; j += kBlock) tile[j] = bounds[t0 + j];
+    int padded = (cnt + kGroup - 1) / kGroup * kGroup;
+    for (int j = cnt + threadIdx.x; j < padded; j += kBlock) tile[j] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+    return cnt;
+}
+
+struct HitAcc { float nearest; int best; int tflag; float txf; };  // txf: t of the last affine-sphere record (thin mode)
+
+// exact closest-hit update for primitive k (wave-uniform), raytracing.cpp:385-403 / :407-418
+__device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3 d, F3 nd, HitAcc& h)
+{
+    if (k < S.ns) {
+        float4 hh = S.sph_hot[k];
+        int xf = S.sph_xf[k];
+        F3 to = o, td = nd;
+        if (xf) {
+            const rtx_xmatrix& im = S.sph_im[k];
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (sphere_test(to, td, hh.x, hh.y, hh.z, hh.w, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) { h.tflag = kTFlag; h.txf = t; } }
+        }
+    } else if (k < S.ns + S.nt) {
+        TriRec T = load_tri(S.tri_hot, k - S.ns);
+        float t, vd;
+        if (triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    } else {
+        const float4* p = S.phot + (size_t)k * 5;
+        float t;
+        if (polygon_test(o, d, p[0], p[1], S.poly_verts, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    }
+}
+
+
+// exact_closest for a wave-uniform primitive k whose hot record sits in lane u's registers
+__device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, const PrimRec& pr, int u, bool pass, F3 o, F3 d, F3 nd, HitAcc& h)
+{
+    const float4 q0 = bcast4(pr.q0, u);
+    if (k < S.ns) {
+        const float4 q4 = bcast4(pr.q4, u);
+        const bool xf = q4.x != 0.0f;
+        F3 to = o, td = nd;
+        if (xf) {  // wave-uniform
+            const float4 q1 = bcast4(pr.q1, u), q2 = bcast4(pr.q2, u), q3 = bcast4(pr.q3, u);
+            rtx_xmatrix im;
+            im.a.x = q1.x; im.a.y = q1.y; im.a.z = q1.z; im.b.x = q1.w;
+            im.b.y = q2.x; im.b.z = q2.y; im.c.x = q2.z; im.c.y = q2.w;
+            im.c.z = q3.x; im.d.x = q3.y; im.d.y = q3.z; im.d.z = q3.w;
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (pass && sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; if (xf) { h.tflag = kTFlag; h.txf = t; } }
+        }
+    } else if (k < S.ns + S.nt) {
+        const float4 q1 = bcast4(pr.q1, u), q2 = bcast4(pr.q2, u), q3 = bcast4(pr.q3, u), q4 = bcast4(pr.q4, u);
+        TriRec T;
+        T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
+        T.vx = q1.x; T.vy = q1.y; T.vz = q1.z; T.area = q1.w;
+        T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
+        T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
+        T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
+        float t, vd;
+        if (pass && triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    } else {
+        const float4 q1 = bcast4(pr.q1, u);
+        float t;
+        if (pass && polygon_test(o, d, q0, q1, S.poly_verts, t)) {
+            if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packet test.  A wave's 64 rays are bounded by a sphere around their origins (co, rho) and a cone
+// around their directions (axis w, half-angle theta).  Each LANE then tests a DIFFERENT primitive's
+// bounding sphere against that packet (64 primitives per instruction instead of one), a ballot turns
+// the answers into a mask, and only primitives in the mask go through the per-ray filter (and, if
+// that passes, the exact test), in index order.  Coherent waves -- primary rays, shadow rays of
+// neighbouring pixels towards one light -- keep a handful of the 10,000 primitives.
+//
+// Conservative by construction: the per-ray filter passes only if the primitive's centre lies within
+// R of the double cone (apex o_i, axis d_i, half-angle atan sqrt(eps/(1-eps))), eps = 1.2e-5 bounding
+// the filter's 2^-18 direction scale and binary32 evaluation error relative to |X|^2; that cone is
+// inside the packet's cone widened by the same angle and thickened by rho.  The test below is
+//      dist(c - co, cone(w, theta')) <= R + rho     i.e.     h cos(theta') <= R + rho + a sin(theta')
+// with a = |w.C|, h^2 = |C|^2 - a^2, squared, every rounding pushed to the passing side.  Waves with an
+// abnormal lane, or a cone wider than ~70 degrees, do not use it (they take the grouped loop).
+// ------------------------------------------------------------------------------------------------
+struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; float c0; bool ok; };  // c0 = cos(theta), rounded down, before the widening by E
+
+__device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int m = 32; m; m >>= 1) v = fmaxf(v, __shfl_xor(v, m)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m); return v; }
+
+// apex_ok: every line of the wave passes through `apex` (shadow rays: their light); the origin sphere then
+// shrinks to the slack that claim needs (the 1e-4 origin bias, the filter's angular tolerance and the
+// direction rounding, both proportional to the distance from the light).
+__device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, bool apex_ok = false, F3 apex = F3{0.0f, 0.0f, 0.0f})
+{
+    Packet P;
+    unsigned long long lm = __ballot(live);
+    bool bad = __any(live && abn) || lm == 0;
+    int src = lm ? (__ffsll((long long)lm) - 1) : 0;
+    // dead lanes borrow a live lane's ray so they do not widen the bounds
+    // (the shuffles are evaluated by EVERY lane, outside the selects: a ds_bpermute under a divergent branch
+    // reads 0 from the lanes that did not take the branch)
+    const F3 so = f3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+    const F3 sd = f3(__shfl(nd.x, src), __shfl(nd.y, src), __shfl(nd.z, src));
+    F3 oo = f3(live ? o.x : so.x, live ? o.y : so.y, live ? o.z : so.z);
+    F3 dd = f3(live ? nd.x : sd.x, live ? nd.y : sd.y, live ? nd.z : sd.z);
+    float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
+    P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+    float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
+    P.rho = wave_max(sqrtf(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
+    if (apex_ok) {  // wave-uniform
+        float ax = oo.x - apex.x, ay = oo.y - apex.y, az = oo.z - apex.z;
+        float maxD = wave_max(sqrtf(ax * ax + ay * ay + az * az));
+        float rho_apex = 1.3e-4f + 3.8e-3f * maxD;
+        if (rho_apex < P.rho) { P.rho = rho_apex; P.co = apex; }
+    }
+    F3 sw = f3(wave_sum(dd.x), wave_sum(dd.y), wave_sum(dd.z));
+    float sn = sqrtf(sw.x * sw.x + sw.y * sw.y + sw.z * sw.z);
+    bad = bad || !(sn > 1e-3f) || !(P.rho < 1e30f);
+    float inv = 1.0f / fmaxf(sn, 1e-3f);
+    P.w = f3(sw.x * inv, sw.y * inv, sw.z * inv);
+    float c = wave_min(P.w.x * dd.x + P.w.y * dd.y + P.w.z * dd.z) - 4e-6f;  // cos(theta), rounded down
+    bad = bad || !(c > 0.35f);
+    c = fminf(c, 1.0f);
+    P.c0 = c;
+    float sT = sqrtf(fmaxf(0.0f, 1.0f - c * c)) + 4e-6f;
+    // widen by the filter's own angular tolerance (3.47e-3 rad) plus slack: E = 3.7e-3 rad
+    const float cosE = 0.99999316f, sinE = 3.7e-3f;
+    float cT = c * cosE - sT * sinE - 4e-6f;           // cos(theta + E), rounded down
+    float sT2 = sT * cosE + c * sinE + 4e-6f;          // sin(theta + E), rounded up
+    bad = bad || !(cT > 0.3f);
+    P.cosT2 = cT * cT;
+    P.sinT = sT2;
+    P.ok = !bad;
+    return P;
+}
+
+// true: the primitive may pass some lane's filter.  b = { c.xyz, -R^2 }.
+__device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
+{
+    float Cx = b.x - P.co.x, Cy = b.y - P.co.y, Cz = b.z - P.co.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;              // rounded down (cancellation, |w| != 1)
+    float Rp = (sqrtf(-b.w) * 1.00001f + P.rho) * 1.00001f + 1e-20f;
+    float rhs = Rp + a * P.sinT;
+    return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // NaN (R = inf, never-bounded primitives) passes
+}
+
+// The same test for ONE ray (origin o, unit or zero direction n): can the sphere b = { c, R } contain
+// the bounding sphere of a primitive whose filter passes for this ray?  The filter's pass region lies
+// inside { c : dist(c, double cone(o, +-n, E)) <= R_prim } (above), so a sphere around such primitives
+// passes if its centre is within its radius of that cone.  Returns the slack, sign bit clear = pass
+// (R = +inf gives +inf).  Used on cluster and sub-cluster spheres by the per-ray traversal; the plain
+// filter is NOT valid on enclosing spheres: its hyperboloid lacks the cone's cross term 2 R a tan(E).
+__device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
+{
+    const float cosE2 = 0.9999783f;  // (cos(3.7e-3) - 4e-6)^2 rounded down
+    const float sinE = 3.705e-3f;    // sin(3.7e-3) rounded up, + 4e-6
+    float Cx = b.x - o.x, Cy = b.y - o.y, Cz = b.z - o.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(n.x * Cx + n.y * Cy + n.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;
+    float rhs = (b.w * 1.00001f + 1e-20f) + a * sinE;
+    return rhs * rhs * 1.00001f - h2 * cosE2;
+}
+
+template <bool PREFETCH>
+__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = base + threadIdx.x;
+    const bool live = q < n;
+    // secondary generations are traced in binned order (k_ray_bin): perm maps sorted position -> ray slot
+    const int i = live ? (perm ? perm[q] : q) : 0;
+    const int ii = i;
+    F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
+    F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
+    F3 nd = normalized(d);
+    const bool abn = ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    HitAcc h;
+    h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
+    const Packet P = make_packet(o, nd, live, abn);
+    int pk_batches = 0, pk_surv = 0;
+    const int nprim = S.ns + S.nt + S.np;
+    // this wave's bitmap of candidate primitives of the current segment (wave-private LDS: the wave's
+    // DS operations execute in issue order, the fences only pin the compiler's ordering)
+    volatile unsigned* bm = reinterpret_cast<volatile unsigned*>(tile) + (threadIdx.x >> 6) * (kSegPrims / 32 + 512);  // + 1024-entry candidate list
+    for (int seg = 0; seg < S.cnseg; seg++) {
+        const int p0 = seg * kSegPrims;
+        const int pn = min(kSegPrims, nprim - p0);
+        const int words = (pn + 31) >> 5;
+        if (P.ok) {  // wave-uniform
+            for (int j = lane; j < words; j += 64) bm[j] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const int c0 = S.cseg[seg], c1 = S.cseg[seg + 1];
+            for (int cb = c0; cb < c1; cb += 64) {
+                const int c = cb + lane;
+                unsigned long long cm = __ballot(c < c1 && packet_test(P, S.ccl[min(c, c1 - 1)]));
+                pk_batches++;
+                while (cm) {
+                    if constexpr (PREFETCH) {
+                        // four clusters' members in flight at a time: one memory round trip per four
+                        int jj[4];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) { jj[a] = cm ? (__ffsll((long long)cm) - 1) : -1; cm &= cm - 1; }
+                        float4 mb[4];
+                        int kk[4];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) {
+                            const size_t m = (size_t)(cb + max(jj[a], 0)) * 64 + lane;
+                            mb[a] = S.cmem[m];
+                            kk[a] = S.cidx[m];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; a++) {
+                            const bool pass = jj[a] >= 0 && kk[a] >= 0 && packet_test(P, mb[a]);
+                            if (pass) atomicOr(const_cast<unsigned*>(bm) + ((kk[a] - p0) >> 5), 1u << ((kk[a] - p0) & 31));
+                            if (jj[a] >= 0) { pk_batches++; pk_surv += __popcll(__ballot(pass)); }
+                        }
+                    } else {
+                        const int j = __ffsll((long long)cm) - 1;
+                        cm &= cm - 1;
+                        const size_t m = (size_t)(cb + j) * 64 + lane;
+                        const float4 mb = S.cmem[m];
+                        const int k = S.cidx[m];
+                        const bool pass = k >= 0 && packet_test(P, mb);
+                        if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
+                        pk_batches++; pk_surv += __popcll(__ballot(pass));
+                    }
+                }
+            }
+        } else {
+            for (int j = lane; j < words; j += 64) bm[j] = (j * 32 + 32 <= pn) ? 0xFFFFFFFFu : ((1u << (pn & 31)) - 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if constexpr (PREFETCH) {
+        // Walk the bitmap in index order: file order, as the reference's loops (:385-418).
+        // Few waves per SIMD (frames below ~4 M rays): a wave's serial chain of dependent loads IS the run time.
+        // The set bits of 32 words are first written out as a list (wave-level prefix sum of the popcounts keeps
+        // the order), then 64 candidates at a time fetch their filter record and hot record with independent
+        // loads -- one memory round trip for the lot -- and the ordered loop reads them from registers.
+        volatile unsigned short* list = reinterpret_cast<volatile unsigned short*>(const_cast<unsigned*>(bm) + kSegPrims / 32);
+        for (int w0 = 0; w0 < words; w0 += 32) {
+            const unsigned wv = (lane < 32 && w0 + lane < words) ? bm[w0 + lane] : 0u;
+            const int cnt = __popc(wv);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            const int tot = __shfl(incl, 63);
+            if (tot == 0) continue;  // wave-uniform
+            {
+                unsigned bits = wv;
+                int pos = incl - cnt;
+                while (bits) {
+                    const int bpos = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    list[pos++] = (unsigned short)(lane * 32 + bpos);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int c0 = 0; c0 < tot; c0 += 64) {
+                const int m = min(64, tot - c0);
+                int k = 0;
+                float4 br = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                PrimRec pr;
+                pr.q0 = pr.q1 = pr.q2 = pr.q3 = pr.q4 = br;
+                if (lane < m) {
+                    k = p0 + (w0 << 5) + (int)list[c0 + lane];
+                    br = S.bounds[k];
+                    pr = load_prim(S.phot, k);
+                }
+                for (int u = 0; u < m; u++) {
+                    const float4 b = bcast4(br, u);
+                    const bool pass = live && (abn || !(filt(fo, fd, b) < 0.0f));
+                    if (__any(pass)) exact_closest_bcast(S, __builtin_amdgcn_readlane(k, u), pr, u, pass, o, d, nd, h);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        } else {
+        // Many waves per SIMD (a 4K frame): latency hides itself and the plain ordered loop costs fewer
+        // instructions -- one scalar-loaded filter record and, on a pass, one exact test per set bit.
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const unsigned wv = (w0 + lane < words) ? bm[w0 + lane] : 0u;
+            unsigned long long nz = __ballot(wv != 0u);
+            while (nz) {
+                const int j = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                unsigned bits = __builtin_amdgcn_readlane(wv, j);
+                while (bits) {
+                    const int bpos = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    const int k = p0 + ((w0 + j) << 5) + bpos;
+                    const float4 br = S.bounds[k];
+                    if (live && (abn || !(filt(fo, fd, br) < 0.0f))) exact_closest(S, k, o, d, nd, h);
+                }
+            }
+        }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (S.pstat && lane == 0) {  // RTX_F_PACKET_STATS only: same-address atomics cost ~12 ns each
+        atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, P.ok ? 1ull : 0ull);
+        atomicAdd(S.pstat + 2, (unsigned long long)pk_batches); atomicAdd(S.pstat + 3, (unsigned long long)pk_surv);
+    }
+    if (live) {
+        L.t[i] = h.nearest;
+        L.prim[i] = (h.best < 0) ? -1 : (h.best | h.tflag);
+    }
+}
+
+
+// Per-ray traversal of the cluster hierarchy, for the generations after the first: reflection and
+// refraction rays of neighbouring pixels leave curved surfaces in all directions, a wave of them is no
+// packet (measured on the benchmark scene: the packet test kept 1,171 of 10,000 primitives per wave at
+// level 1, against 17 at level 0).  Every LANE walks the hierarchy for its own ray instead:
+//   1. the filter against every cluster sphere (wave-uniform loop, 64 clusters per round, a bit per pass),
+//   2. lanes step through their own passing clusters in lockstep and run the filter against the 64
+//      members (per-lane gathers, sign bits AND-ed over groups of 8); members that pass are appended to
+//      the lane's candidate list in LDS,
+//   3. whenever a list is nearly full, and at the end, all lanes run the exact tests of their lists in
+//      lockstep.
+// The candidates of a ray arrive in cluster order, not file order, so the reference's sequential scan
+// (:385-418) is restated order-independently.  With H = the accepted hits (t_k, k):
+//   * nearest/best = the lexicographic minimum of (t_k, k) over hits with t_k < Max_t: the scan keeps
+//     the first of equal t's because it updates on strict `<` only;
+//   * a triangle that wins resets the `transformed` flag and only triangles follow it, so the flag is
+//     0 when best is a triangle; otherwise it is 1 iff some affine sphere k was a record when the scan
+//     reached it: t_k < Max_t and t_j > t_k for every hit j < k.  Affine-sphere clusters are traversed
+//     FIRST; their hits form a list in which (j < k, t_j <= t_k) removes k, and every later hit of a
+//     plain sphere removes entries the same way.  The flag is "list not empty".  The list holds the
+//     staircase of affine hits (index up, t down), 4 entries; a fifth sends the lane to the ordered
+//     scan over every primitive at the end (wave-uniform loop, only the flagged lanes active).
+// Rays the filter does not cover (ray_abnormal) take every cluster and every member.
+constexpr int kCandCap = 24;   // candidate list entries per lane (LDS)
+constexpr int kQBatch = 32;    // clusters per round; the lane's queue of passing clusters holds as many
+constexpr int kAffList = 4;
+
+constexpr int kLaneLds = kCandCap * 64 * 4 + kQBatch * 64 * 2;  // LDS bytes per wave: candidate lists + cluster queues
+
+struct LexAcc {
+    float nearest; int best;
+    float at[kAffList]; int ak[kAffList];
+    bool overflow;
+};
+
+// exact test of primitive k (per lane) with the order-independent update.  The primitive's 80-byte hot
+// record (SceneDev::phot) comes in with five independent loads: one memory round trip per round of the
+// lockstep loop, where sph_hot -> sph_xf -> sph_im was a chain of three.
+__device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
+{
+    const float4* p = S.phot + (size_t)k * 5;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    if (k < S.ns) {
+        const bool xf = q4.x != 0.0f;
+        F3 to = o, td = nd;
+        if (xf) {
+            rtx_xmatrix im;
+            im.a.x = q1.x; im.a.y = q1.y; im.a.z = q1.z; im.b.x = q1.w;
+            im.b.y = q2.x; im.b.z = q2.y; im.c.x = q2.z; im.c.y = q2.w;
+            im.c.z = q3.x; im.d.x = q3.y; im.d.y = q3.z; im.d.z = q3.w;
+            to = inv_apply(o, im);
+            td = normalized(inv_apply(d, im));
+        }
+        float t;
+        if (sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+            if (xf) {
+                if (t < kMaxT) {
+                    bool killed = false;
+#pragma unroll
+                    for (int e = 0; e < kAffList; e++) killed = killed || (h.ak[e] >= 0 && h.ak[e] < k && h.at[e] <= t);
+                    if (!killed) {
+                        bool placed = false;
+#pragma unroll
+                        for (int e = 0; e < kAffList; e++) {
+                            if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+                            if (!placed && h.ak[e] < 0) { h.ak[e] = k; h.at[e] = t; placed = true; }
+                        }
+                        if (!placed) h.overflow = true;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < kAffList; e++)
+                    if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+            }
+        }
+    } else if (k >= S.ns + S.nt) {
+        float t;
+        if (polygon_test(o, d, q0, q1, S.poly_verts, t)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+        }
+    } else {
+        TriRec T;
+        T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
+        T.vx = q1.x; T.vy = q1.y; T.vz = q1.z; T.area = q1.w;
+        T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
+        T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
+        T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
+        float t, vd;
+        if (triangle_test(o, d, T, t, vd)) {
+            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+        }
+    }
+}
+
+__device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int q, float4* tile, const int* perm,
+                                              const int sub, const int nsub)
+{
+    const int lane = threadIdx.x & 63;
+    const bool live = q < n;
+    const int i = live ? (perm ? perm[q] : q) : 0;
+    F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
+    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    F3 nd = normalized(d);
+    const bool abn = live && ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    LexAcc h;
+    h.nearest = kMaxT; h.best = -1; h.overflow = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
+    int* cand = reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + lane;  // cand[slot * 64]
+    unsigned short* queue = reinterpret_cast<unsigned short*>(reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + kCandCap * 64) + lane;  // queue[slot * 64]
+    int ncand = 0, flushes = 0, tested = 0;
+    auto flush = [&]() {
+        const int maxn = (int)wave_max((float)ncand);
+        for (int a = 0; a < maxn; a++)
+            if (a < ncand) exact_lex(S, cand[a * 64], o, d, nd, h);
+        tested += ncand; flushes++;
+        ncand = 0;
+    };
+    const int ncl = S.cseg[S.cnseg];
+    for (int phase = 0; phase < 2; phase++) {
+        const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
+        for (int cb = cbeg; cb < cend; cb += kQBatch) {
+            // (1) this round's cluster spheres: one coalesced load, then lane u's record is broadcast
+            unsigned cmask = 0u;
+            const int ce = min(kQBatch, cend - cb);
+            const int myc = S.corder[min(cb + (lane & (kQBatch - 1)), cend - 1)];
+            const float4 mine = S.cclR[myc];
+            for (int u = 0; u < ce; u++) {
+                float4 b;
+                b.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), u));
+                b.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), u));
+                b.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), u));
+                b.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.w), u));
+                if (!(cone_slack(o, nd, b) < 0.0f)) cmask |= 1u << u;
+            }
+            if (abn) cmask = (ce == 32) ? ~0u : ((1u << ce) - 1u);
+            if (!live) cmask = 0u;
+            if (phase == 1 && nsub == 4) cmask &= 0x11111111u << sub;  // split generation: this lane's quarter of the clusters
+            // (2) sub-cluster spheres of the lane's own passing clusters -> queue of (cluster slot, group mask)
+            int nq = 0;
+            while (__any(cmask != 0u)) {
+                const bool has = cmask != 0u;
+                const int u = has ? (__ffs(cmask) - 1) : 0;
+                cmask &= cmask - 1u;  // 0 stays 0
+                const int cid = __shfl(myc, u);
+                const float4* srec = S.csubR + (size_t)cid * 8;
+                unsigned gmask = 0u;
+#pragma unroll
+                for (int v = 0; v < 8; v++)
+                    if (!(cone_slack(o, nd, srec[v]) < 0.0f)) gmask |= 1u << v;
+                if (abn) gmask = 0xFFu;
+                if (has && gmask) { queue[nq * 64] = (unsigned short)((u << 8) | gmask); nq++; }
+            }
+            // (3) the members of the lane's own passing groups, one group of 8 per step
+            int qi = 0, cid = 0;
+            unsigned gm = 0u;
+            while (true) {
+                const bool refill = gm == 0u && qi < nq;
+                const unsigned e = refill ? (unsigned)queue[qi * 64] : 0u;
+                const int cnext = __shfl(myc, (int)(e >> 8));  // every lane takes part: ds_bpermute reads 0 from inactive lanes
+                if (refill) { qi++; gm = e & 0xFFu; cid = cnext; }
+                if (!__any(gm != 0u)) break;
+                const bool hasg = gm != 0u;
+                const int g = hasg ? (__ffs(gm) - 1) : 0;
+                gm &= gm - 1u;
+                const float4* mrec = S.cmem + (size_t)cid * 64 + g * 8;
+                const int* midx = S.cidx + (size_t)cid * 64 + g * 8;
+                float4 mb[kGroup];
+#pragma unroll
+                for (int v = 0; v < kGroup; v++) mb[v] = mrec[v];
+                unsigned acc = 0xFFFFFFFFu;
+#pragma unroll
+                for (int v = 0; v < kGroup; v++) acc &= __float_as_uint(filt(fo, fd, mb[v]));
+                if (hasg && (abn || (int)acc >= 0)) {
+#pragma unroll
+                    for (int v = 0; v < kGroup; v++) {
+                        if (abn || !(filt(fo, fd, mb[v]) < 0.0f)) {
+                            const int k = midx[v];
+                            if (k >= 0) { cand[ncand * 64] = k; ncand++; }
+                        }
+                    }
+                }
+                if (__any(ncand > kCandCap - kGroup)) flush();
+            }
+        }
+        flush();  // phase 0: every affine-sphere hit is known before the first plain sphere is tested
+    }
+    if (nsub == 4) {
+        // the four lanes of a ray hold the same affine list (phase 0 is not split) with their own kills, and
+        // their own nearest hit: an entry lives if no lane removed it, the lexicographic minimum wins
+#pragma unroll
+        for (int m = 1; m <= 2; m <<= 1) {
+            const float t2 = __shfl_xor(h.nearest, m);
+            const int b2 = __shfl_xor(h.best, m);
+            if (t2 < h.nearest || (t2 == h.nearest && b2 < h.best)) { h.nearest = t2; h.best = b2; }
+#pragma unroll
+            for (int e = 0; e < kAffList; e++) h.ak[e] = min(h.ak[e], __shfl_xor(h.ak[e], m));
+            h.overflow = h.overflow || (__shfl_xor((int)h.overflow, m) != 0);
+        }
+    }
+    bool alive = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) alive = alive || h.ak[e] >= 0;
+    float nearest = h.nearest;
+    int best = h.best;
+    int tflag = (best >= 0 && best < S.ns && alive) ? kTFlag : 0;
+    const bool slow = live && h.overflow;
+    if (__any(slow)) {
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        const int nprim = S.ns + S.nt + S.np;
+        for (int k = 0; k < nprim; k++) {
+            const float4 b = S.bounds[k];
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
+        }
+        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+    }
+    if (S.pstat) {
+        const unsigned long long sl = __ballot(slow);
+        const unsigned long long ab = __ballot(abn);
+        const float tot = wave_sum(live ? (float)tested : 0.0f);
+        if (lane == 0) {
+            atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, (unsigned long long)__popcll(sl) + ((unsigned long long)__popcll(ab) << 32));
+            atomicAdd(S.pstat + 2, (unsigned long long)flushes); atomicAdd(S.pstat + 3, (unsigned long long)tot);
+        }
+    }
+    if (live && sub == 0) {
+        L.t[i] = nearest;
+        L.prim[i] = (best < 0) ? -1 : (best | tflag);
+    }
+}
+
+// Thin generations (deep bounces: few, incoherent rays).  A workgroup takes only 64 rays and its
+// four waves split the primitive list into four contiguous slices, so a generation of a few
+// thousand rays still puts a wave on every SIMD and the serial walk per wave is 4x shorter.
+// The slices are merged in index order, which reproduces the sequential scan exactly: slice p's
+// nearest hit wins iff it is strictly nearer than everything before it, and the reference's sticky
+// `transformed` flag (:396-399) is set iff some slice's last affine-sphere record beats the minimum
+// of the slices before it.
+constexpr int kThinRays = 1 << 18;
+constexpr int kThinTile = kTile / 4;
+
+__device__ __forceinline__ int stage_thin(float4* mt, const float4* bounds, int t0, int end, int lane)
+{
+    int cnt = max(0, min(kThinTile, end - t0));
+    for (int j = lane; j < cnt; j += 64) mt[j] = bounds[t0 + j];
+    int padded = (cnt + kGroup - 1) / kGroup * kGroup;
+    for (int j = cnt + lane; j < padded; j += 64) mt[j] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+    return cnt;
+}
+
+__device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& L, const int n, float4* tile)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;  // the four waves hold the same 64 rays
+    const bool live = i < n;
+    const int ii = live ? i : 0;
+    F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
+    F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
+    F3 nd = normalized(d);
+    const bool abn = ray_abnormal(o, d, nd, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(accinit));
+    HitAcc h;
+    h.nearest = kMaxT; h.best = -1; h.tflag = 0; h.txf = kMaxT;
+    const int nprim = S.ns + S.nt + S.np;
+    const int SL = ((nprim + kGroup - 1) / kGroup + 3) / 4 * kGroup;  // primitives per slice, whole groups
+    const int p0 = min(w * SL, nprim), p1 = min(p0 + SL, nprim);
+    const int T = (SL + kThinTile - 1) / kThinTile;
+    float4* mt = tile + w * kThinTile;
+    for (int tt = 0; tt < T; tt++) {
+        __syncthreads();
+        const int t0 = p0 + tt * kThinTile;
+        const int cnt = stage_thin(mt, S.bounds, t0, p1, lane);
+        __syncthreads();
+        for (int g = 0; g < cnt; g += kGroup) {
+            unsigned acc = accinit;
+#pragma unroll
+            for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, mt[g + u]));
+            if ((int)acc >= 0) {
+                int gend = min(kGroup, cnt - g);
+                for (int u = 0; u < gend; u++)
+                    if (live && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h);
+            }
+        }
+    }
+    __syncthreads();
+    float* rt = reinterpret_cast<float*>(tile);
+    int* rb = reinterpret_cast<int*>(tile) + 256;
+    float* rx = reinterpret_cast<float*>(tile) + 512;
+    rt[threadIdx.x] = h.nearest; rb[threadIdx.x] = h.best; rx[threadIdx.x] = h.txf;
+    __syncthreads();
+    if (w == 0 && live) {
+        float m = kMaxT;
+        int best = -1, flag = 0;
+        for (int p = 0; p < 4; p++) {
+            if (rx[p * 64 + lane] < m) flag = kTFlag;
+            float tp = rt[p * 64 + lane];
+            if (tp < m) { m = tp; best = rb[p * 64 + lane]; }
+        }
+        if (best >= S.ns) flag = 0;  // a triangle won: :416
+        L.t[i] = m;
+        L.prim[i] = (best < 0) ? -1 : (best | flag);
+    }
+}
+
+template <bool PREFETCH>
+__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays, const int* perm)
+{
+    __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps (2 KiB) and candidate lists (2 KiB)
+    static_assert((kSegPrims / 32 + 512) * 4 * (kBlock / 64) <= kTile * 16, "bitmaps and lists fit");
+    const int n = *nrays;
+    if (n > kThinRays) {
+        const int base = blockIdx.x * kBlock;
+        if (base >= n) return;  // block-uniform
+        closest_packet<PREFETCH>(S, L, n, base, tile, perm);
+    } else {
+        if (blockIdx.x * 64 >= n) return;
+        closest_thin(S, L, n, tile);
+    }
+}
+
+// Generations of at most kSplitClosest rays put FOUR lanes on every ray (64 rays per workgroup): the lanes
+// share the affine-sphere clusters and take a quarter of the others each, and merge at the end.  A thin
+// generation has fewer waves than the chip has SIMDs; its run time is one wave's serial walk, now a
+// third as long.
+constexpr int kSplitClosest = 1 << 17;
+constexpr size_t kPrefetchRays = (size_t)1 << 22;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
+
+__global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
+{
+    __shared__ float4 tile[kLaneLds * (kBlock / 64) / 16];  // the four waves' candidate lists and cluster queues (40 KiB)
+    const int n = *nrays;
+    const int* pm = n > kThinRays ? perm : nullptr;
+    if (n <= kSplitClosest) {
+        if (blockIdx.x * 64 >= n) return;  // block-uniform
+        closest_lanes(S, L, n, blockIdx.x * 64 + (threadIdx.x >> 2), tile, pm, threadIdx.x & 3, 4);
+    } else {
+        if (blockIdx.x * kBlock >= n) return;
+        closest_lanes(S, L, n, blockIdx.x * kBlock + threadIdx.x, tile, pm, 0, 1);
+    }
+}
+
+
+}  // namespace rtx
+#endif

@@ -1,0 +1,477 @@
+// rtx_shadow.hip.h -- shadow rays: light-space binning (bin / scan / scatter) and k_shadow_pass (packets with their apex at the light, affine strip test)
+// Part of the one translation unit rtx_device.hip (device code, namespace rtx); not a stand-alone header.
+#ifndef RTX_SHADOW_HIP_H_
+#define RTX_SHADOW_HIP_H_
+
+namespace rtx {
+
+// exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
+__device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld, F3 nld)
+{
+    if (k < S.ns) {
+        float4 hh = S.sph_hot[k];
+        F3 td = nld;
+        if (S.sph_xf[k]) td = normalized(inv_apply(ld, S.sph_im[k]));
+        float t;
+        return sphere_test(o, td, hh.x, hh.y, hh.z, hh.w, t);
+    }
+    TriRec T = load_tri(S.tri_hot, k - S.ns);
+    float t, vd;
+    return triangle_test(o, ld, T, t, vd);
+}
+
+// Shadow rays (raytracing.cpp:560-589) are any-hit: which primitive blocks the light first does not
+// matter, only whether one does.  So they are not traced in file order in one long loop.  They are
+// materialised once per generation into a queue sorted by (light, direction cell) (k_shadow_bin, k_scan_*,
+// k_shadow_scatter) and traced by k_shadow_pass as packets with their apex at the light: plain spheres
+// and triangles through the shadow cluster hierarchy, affine spheres through a strip test of their own.
+struct ShadowQ { float *ox, *oy, *oz, *dx, *dy, *dz; int* id; };
+
+// Light-space binning.  Every shadow ray's line passes through its light, so rays towards one light
+// that leave it in nearly the same direction are nearly the same line, wherever their hit points
+// are.  The rays of a generation are therefore counting-sorted by (light, direction cell) -- an
+// octahedral G x G map of the direction, cells in Morton order -- before the passes: a wave then
+// holds 64 rays inside a cone of a degree or so with its apex AT the light, the packet test keeps a
+// few dozen of the 10,000 primitives, and the 64 rays tend to be blocked by the same primitive.
+__device__ __forceinline__ unsigned morton8(unsigned x)
+{
+    x &= 0xffu;
+    x = (x | (x << 4)) & 0x0f0fu;
+    x = (x | (x << 2)) & 0x3333u;
+    x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+
+__device__ __forceinline__ int light_cell(F3 v, int G)
+{
+    float s = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+    float inv = 1.0f / fmaxf(s, 1e-30f);
+    float px = v.x * inv, py = v.y * inv;
+    if (v.z < 0.0f) {
+        float qx = (1.0f - fabsf(py)) * (px >= 0.0f ? 1.0f : -1.0f);
+        float qy = (1.0f - fabsf(px)) * (py >= 0.0f ? 1.0f : -1.0f);
+        px = qx; py = qy;
+    }
+    // fminf/fmaxf drop NaN operands, so a NaN direction lands in cell 0
+    int cx = (int)fminf(fmaxf((px * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
+    int cy = (int)fminf(fmaxf((py * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
+    return (int)(morton8((unsigned)cx) | (morton8((unsigned)cy) << 1));
+}
+
+
+// Secondary rays (reflection / refraction) of neighbouring pixels leave from different surfaces in
+// different directions.  Before a generation k >= 1 is traced its rays are counting-sorted by
+// (origin cell of a 16^3 grid over the scene box, 16 x 16 octahedral direction cell), Morton order,
+// and traced in that order through a permutation, so that a wave is again a packet with a small
+// origin sphere and a narrow cone.  Generations too thin for packet mode skip the sort.
+constexpr int kRayBins = 1 << 20;
+
+__device__ __forceinline__ unsigned morton3_4(unsigned x)  // 4 bits -> every third bit
+{
+    x &= 0xfu;
+    x = (x | (x << 4)) & 0x0c3u;
+    x = (x | (x << 2)) & 0x249u;
+    return x;
+}
+
+__device__ __forceinline__ int ray_key(const SceneDev& S, F3 o, F3 d)
+{
+    int cx = (int)fminf(fmaxf((o.x - S.box_lo.x) * S.box_inv.x, 0.0f), 15.0f);
+    int cy = (int)fminf(fmaxf((o.y - S.box_lo.y) * S.box_inv.y, 0.0f), 15.0f);
+    int cz = (int)fminf(fmaxf((o.z - S.box_lo.z) * S.box_inv.z, 0.0f), 15.0f);
+    unsigned oc = morton3_4((unsigned)cx) | (morton3_4((unsigned)cy) << 1) | (morton3_4((unsigned)cz) << 2);
+    return (int)((oc << 8) | (unsigned)light_cell(d, 16));
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_bin(SceneDev S, LevelDev L, const int* nrays, int* hist, int* rank)
+{
+    const int n = *nrays;
+    if (n <= kThinRays) return;  // thin generations are not traced in packet mode
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    int key = -1;
+    if (live) key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
+    int myrank = 0;
+    unsigned long long pending = __ballot(live);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(live && key == k0) & pending;
+        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
+        base = __shfl(base, leader);
+        if ((same >> (threadIdx.x & 63)) & 1ull) myrank = base + prefix;
+        pending &= ~same;
+    }
+    if (live) rank[i] = myrank;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ray_scatter(SceneDev S, LevelDev L, const int* nrays, const int* offs, const int* rank, int* perm)
+{
+    const int n = *nrays;
+    if (n <= kThinRays) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
+    perm[offs[key] + rank[i]] = i;
+}
+
+struct ShadowRay { F3 o, ld; int key; };
+
+__device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& S, const LevelDev& L, int j, int li, int G)
+{
+    const rtx_light& Lt = S.lights[li];
+    F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
+    F3 nn = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
+    ShadowRay r;
+    r.ld = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));                  // :561-562
+    r.o = f3(ip.x + nn.x * kBias, ip.y + nn.y * kBias, ip.z + nn.z * kBias);                       // :568
+    r.key = li * G * G + light_cell(r.ld, G);
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow_bin(SceneDev S, LevelDev L, const int* nnodes, int G, int* hist, int* rank)
+{
+    const int n = *nnodes;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int li = blockIdx.y;
+    const bool live = j < n;
+    int key = -1;
+    if (live) {
+        key = make_shadow_ray(S, L, j, li, G).key;
+        L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
+    }
+    // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key
+    // per wave (leader election on the first pending lane's key) instead of one per ray.
+    int myrank = 0;
+    unsigned long long pending = __ballot(live);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(live && key == k0) & pending;
+        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
+        base = __shfl(base, leader);
+        if (live && key == k0 && ((same >> (threadIdx.x & 63)) & 1ull)) myrank = base + prefix;
+        pending &= ~same;
+    }
+    if (live) rank[li * n + j] = myrank;
+}
+
+// Exclusive scan of the bin counts in three small launches: per-block scan of 1024 bins, scan of the
+// block sums, add-back.  nbins <= 4 Mi, so at most 4096 block sums.
+// align > 1 (shadow queues): every group of 1024 bins -- a 32 x 32 square of one light's direction map --
+// starts at a slot that is a multiple of `align` (64), so no wave straddles two lights or a long jump of
+// the Morton curve; the slots skipped are marked as padding (id = -1) by k_scan_add.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int* hist, int* offs, int nbins, int* bsum, int* braw, int align)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x, b = blockIdx.x * 1024 + t;
+    const int v = (b < nbins) ? hist[b] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int x = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if (b < nbins) offs[b] = part[t] - v;
+    if (t == 1023) {
+        braw[blockIdx.x] = part[1023];
+        bsum[blockIdx.x] = (part[1023] + align - 1) / align * align;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int* qcount)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = min(t * per, nblocks), b1 = min(b0 + per, nblocks);
+    int sum = 0;
+    for (int b = b0; b < b1; b++) sum += bsum[b];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int x = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int b = b0; b < b1; b++) { int v = bsum[b]; bsum[b] = run; run += v; }
+    if (t == 1023) *qcount = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, int* pad_ids)
+{
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    const int start = bsum[blockIdx.x];
+    if (b < nbins) offs[b] += start;
+    if (pad_ids) {
+        const int raw = braw[blockIdx.x];
+        const int pad = (raw + align - 1) / align * align - raw;
+        if ((int)threadIdx.x < pad) pad_ids[start + raw + threadIdx.x] = -1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev L, const int* nnodes, int G, const int* offs,
+                                                           const int* rank, ShadowQ Q)
+{
+    const int n = *nnodes;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int li = blockIdx.y;
+    if (j >= n) return;
+    ShadowRay r = make_shadow_ray(S, L, j, li, G);
+    const int q = offs[r.key] + rank[li * n + j];
+    Q.ox[q] = r.o.x; Q.oy[q] = r.o.y; Q.oz[q] = r.o.z;
+    Q.dx[q] = r.ld.x; Q.dy[q] = r.ld.y; Q.dz[q] = r.ld.z;
+    Q.id[q] = li * L.cap + j;
+}
+
+// Affine spheres.  The reference maps only the
+// DIRECTION into object space for shadow rays (:571-576); filter = line (o, q = ld*A) against the
+// sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
+__device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, float4 m2, float4 m3)
+{
+    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
+    float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
+    float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
+    float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
+    float X = o.x - m2.y, Y = o.y - m2.z, Z = o.z - m2.w;
+    float bq = __builtin_fmaf(qx, X, __builtin_fmaf(qy, Y, qz * Z));
+    float qq = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+    float cc = __builtin_fmaf(X, X, __builtin_fmaf(Y, Y, __builtin_fmaf(Z, Z, m3.x)));
+    return __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
+}
+
+// One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
+__device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
+                                                   unsigned char* lit, const int lit_cap, const int part, const int parts)
+{
+    const int c0 = 0, c1 = S.nsb;
+    const int lane = threadIdx.x & 63;
+    const int i = base + threadIdx.x;
+    const int ii = (i < n) ? i : 0;
+    const int id = Qi.id[ii];
+    const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
+    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
+    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+    F3 nld = normalized(ld);
+    const bool abn = ray_abnormal(o, ld, nld, S.guard);
+    const bool use = live && !abn;
+    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+    bool done = !live;
+    int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0, pk_aff = 0;
+    auto bcast4 = [](float4 v, int u) {
+        float4 r;
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), u));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), u));
+        r.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.z), u));
+        r.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.w), u));
+        return r;
+    };
+    // A wave is traced as ONE packet when its 64 rays make a usable one.  At a seam -- the last rays towards
+    // one light followed by the first towards the next, a jump of the Morton curve over the direction map,
+    // an abnormal ray -- they do not: the lanes are then split into aligned blocks of 32, 16, ... 1, each
+    // traced as a packet of its own with the other lanes switched off.  A single ray that makes no packet
+    // (an abnormal one) takes the transposed scan below.
+    const int li = id / lit_cap;
+    unsigned long long remaining = __ballot(live), fallback = 0ull;
+    int size = 64;
+    while (remaining) {
+        const int first = __ffsll((long long)remaining) - 1;
+        const int lo = first & ~(size - 1);
+        const unsigned long long blk = ((size == 64) ? ~0ull : (((1ull << size) - 1ull) << lo)) & remaining;
+        const bool sel = (blk >> lane) & 1ull;
+        // all of the block's lanes aimed at the same light?  then their lines share that point
+        const int li0 = __builtin_amdgcn_readlane(li, first);
+        const bool one_light = __all(!sel || li == li0) && li0 >= 0 && li0 < S.nl;
+        F3 apex = f3(0.0f, 0.0f, 0.0f);
+        if (one_light) apex = f3(S.lights[li0].point);
+        const Packet P = make_packet(o, nld, sel, abn, one_light, apex);
+        if (!P.ok && size > 1) { size >>= 1; continue; }
+        remaining &= ~blk;
+        if (!P.ok) { fallback |= blk; continue; }
+        pk_blocks++; pk_ok += P.ok ? 1 : 0;
+        // lanes outside the block sit this round out
+        const bool done_keep = done;
+        const F3 fo_keep = fo, fd_keep = fd;
+        if (!sel) { done = true; fo = f3(1e18f, 0.0f, 0.0f); fd = f3(0.0f, 0.0f, 0.0f); }
+        if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
+            bool out = __all(done);
+            for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+                const int c = cb + lane;
+                unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+                pk_batches++;
+                while (cm && !out) {
+                    const int j = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    const size_t m = (size_t)(cb + j) * 64 + lane;
+                    const float4 mb = S.smem[m];
+                    const int k = S.sidx[m];
+                    unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
+                    pk_batches++; pk_surv += __popcll(mm);
+                    while (mm) {
+                        const int u = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const float4 br = bcast4(mb, u);
+                        if (!done && !(filt(fo, fd, br) < 0.0f)) {
+                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                    out = __all(done);
+                }
+            }
+            // Affine spheres (raytracing.cpp:571-576: only the DIRECTION is mapped, q = ld*A, the origin stays
+            // in world space).  Packet test, one sphere per lane: with a reference point Lr (the light, or the
+            // packet's origin centre) every origin is Lr - D w + e, D in [Dmin, Dmax], |e| <= rperp, and every
+            // direction is (w + delta) A with |delta| <= chord.  For a unit axis a orthogonal to q_w = w A the
+            // point p of a line nearest the sphere centre c has a.(p - Lr) = -D (a.w) + a.e + s a.(delta A),
+            // |s| |q| = |p - o| <= |c - o|, and the per-ray filter (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)
+            // passes only if |p - c| <= R + tan(alpha) |p - o|, tan^2(alpha) <= 2^-13 + 2^-19.  So a sphere some
+            // ray can pass has, on BOTH axes of an orthonormal pair around q_w,
+            //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
+            //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
+            // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
+            if (!out && S.naff > 0) {
+                const F3 Lr = one_light ? apex : P.co;
+                const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
+                const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
+                const F3 rel = f3(Lr.x - oo.x, Lr.y - oo.y, Lr.z - oo.z);
+                const float D = P.w.x * rel.x + P.w.y * rel.y + P.w.z * rel.z;
+                const F3 e = f3(D * P.w.x - rel.x, D * P.w.y - rel.y, D * P.w.z - rel.z);
+                const float Dmin = wave_min(D), Dmax = wave_max(D);
+                const float Dfar = wave_max(sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
+                const float rperp = wave_max(sqrtf(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
+                const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * P.c0)) * 1.0001f + 2e-5f;  // |ld - w| over the block
+                for (int a0 = part * 64; a0 < S.naff && !out; a0 += 64 * parts) {
+                    const int ai = min(a0 + lane, S.naff - 1);
+                    const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+                    const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+                    bool pass = a0 + lane < S.naff;
+                    {
+                        const F3 w = P.w;
+                        // rows of A: ra = (m0.x m0.y m0.z), rb = (m0.w m1.x m1.y), rc = (m1.z m1.w m2.x); q = w A
+                        float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
+                        float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
+                        float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
+                        const float qn = sqrtf(qx * qx + qy * qy + qz * qz);
+                        const float R = sqrtf(-m3.x) * 1.00001f;   // +inf for records that always pass, NaN never arises (m3.x <= 0)
+                        const float nF = sqrtf(m0.x * m0.x + m0.y * m0.y + m0.z * m0.z + m0.w * m0.w + m1.x * m1.x + m1.y * m1.y +
+                                               m1.z * m1.z + m1.w * m1.w + m2.x * m2.x) * 1.00001f;  // >= ||A||_2
+                        const float qlow = qn * 0.99999f - chord * nF;  // <= |ld A| for every ray of the block
+                        if (qn < 1e18f && R < 1e18f && nF < 1e18f && qlow > 0.25f * qn && qlow > 1e-18f) {
+                            const float inv = 1.0f / qn;
+                            qx *= inv; qy *= inv; qz *= inv;
+                            // orthonormal pair around q (Duff et al.), good to ~1e-6
+                            const float sg = (qz >= 0.0f) ? 1.0f : -1.0f;
+                            const float aa = -1.0f / (sg + qz);
+                            const float bb = qx * qy * aa;
+                            const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
+                            const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
+                            const F3 E = f3(m2.y - Lr.x, m2.z - Lr.y, m2.w - Lr.z);
+                            // |c - o| <= far for every ray of the block: o = Lr - D w + e
+                            const F3 f1 = f3(E.x + Dmin * w.x, E.y + Dmin * w.y, E.z + Dmin * w.z);
+                            const F3 f2 = f3(E.x + Dmax * w.x, E.y + Dmax * w.y, E.z + Dmax * w.z);
+                            const float far = sqrtf(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + rperp;
+                            // a.(delta A) = delta.(A a^T): |.| <= chord |A a^T|; 1e-5 covers the pair's own orthogonality error
+                            const F3 v1 = f3(m0.x * ax1.x + m0.y * ax1.y + m0.z * ax1.z, m0.w * ax1.x + m1.x * ax1.y + m1.y * ax1.z, m1.z * ax1.x + m1.w * ax1.y + m2.x * ax1.z);
+                            const F3 v2 = f3(m0.x * ax2.x + m0.y * ax2.y + m0.z * ax2.z, m0.w * ax2.x + m1.x * ax2.y + m1.y * ax2.z, m1.z * ax2.x + m1.w * ax2.y + m2.x * ax2.z);
+                            const float g1 = (chord * sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) + 1e-5f * nF) / qlow;
+                            const float g2 = (chord * sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) + 1e-5f * nF) / qlow;
+                            const float base_T = (R + rperp + 0.0112f * far) * 1.0001f + 1e-5f * (far + Dfar);
+                            const float T1 = base_T + g1 * far * 1.0001f, T2 = base_T + g2 * far * 1.0001f;
+                            const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
+                            const float t2 = ax2.x * w.x + ax2.y * w.y + ax2.z * w.z, e2 = ax2.x * E.x + ax2.y * E.y + ax2.z * E.z;
+                            const float lo1 = fminf(-Dmin * t1, -Dmax * t1), hi1 = fmaxf(-Dmin * t1, -Dmax * t1);
+                            const float lo2 = fminf(-Dmin * t2, -Dmax * t2), hi2 = fmaxf(-Dmin * t2, -Dmax * t2);
+                            if (e1 < lo1 - T1 || e1 > hi1 + T1 || e2 < lo2 - T2 || e2 > hi2 + T2) pass = false;
+                        }
+                    }
+                    unsigned long long am = __ballot(pass);
+                    pk_batches++; pk_aff += __popcll(am);
+                    while (am) {
+                        const int u = __ffsll((long long)am) - 1;
+                        am &= am - 1;
+                        const float4 b0 = bcast4(m0, u), b1 = bcast4(m1, u), b2 = bcast4(m2, u), b3 = bcast4(m3, u);
+                        if (!done && !(filt_affine(o, ld, b0, b1, b2, b3) < 0.0f)) {
+                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld)) {
+                                done = true;
+                                fo = f3(1e18f, 0.0f, 0.0f);
+                                fd = f3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                    out = __all(done);
+                }
+            }
+        }
+        if (!sel) { done = done_keep; fo = fo_keep; fd = fd_keep; }
+    }
+    // Rays that fit no packet (abnormal ones included) are traced one at a time, TRANSPOSED: the ray is
+    // broadcast and the 64 lanes take 64 different primitives each round, filter and exact test.
+    const int pk_fb = __popcll(fallback);
+    while (fallback) {
+        const int r = __ffsll((long long)fallback) - 1;
+        fallback &= fallback - 1;
+        auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+        const F3 ro = f3(bc(o.x), bc(o.y), bc(o.z)), rl = f3(bc(ld.x), bc(ld.y), bc(ld.z)), rn = f3(bc(nld.x), bc(nld.y), bc(nld.z));
+        const F3 rfo = f3(bc(fo.x), bc(fo.y), bc(fo.z)), rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));
+        const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
+        bool blocked = false;
+        for (int g = c0 + part * 64; g < c1 && !blocked; g += 64 * parts) {
+            const int gi = g + lane;
+            bool hit = false;
+            if (gi < c1) {
+                const float4 rec = S.sbounds[gi];
+                if (rabn || !(filt(rfo, rfd, rec) < 0.0f)) hit = exact_any(S, S.sorder[gi], ro, rl, rn);
+            }
+            blocked = __any(hit);
+        }
+        for (int a0 = part * 64; a0 < S.naff && !blocked; a0 += 64 * parts) {
+            const int ai = a0 + lane;
+            bool hit = false;
+            if (ai < S.naff) {
+                const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+                const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+                if (rabn || !(filt_affine(ro, rl, m0, m1, m2, m3) < 0.0f)) hit = exact_any(S, __float_as_int(m3.y), ro, rl, rn);
+            }
+            blocked = __any(hit);
+        }
+        if (lane == r && blocked) done = true;
+    }
+    if (S.pstat && lane == 0) {
+        atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
+        atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv + ((unsigned long long)pk_aff << 32));
+    }
+    if (live && done) lit[id] = 0;
+}
+
+// A thin generation (<= kSplitRays shadow rays) is traced by kSplit workgroups per 256 rays, each taking every
+// kSplit-th cluster and affine batch: a ray is blocked if ANY part finds a blocker (each just clears lit[id]),
+// and the serial walk per wave -- what bounds the run time when there are fewer waves than SIMDs can hold --
+// is kSplit times shorter.
+constexpr int kSplit = 4;
+constexpr int kSplitRays = 1 << 21;
+
+__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
+{
+    const int n = *cnt_in;
+    const int parts = (n <= kSplitRays) ? kSplit : 1;
+    const int base = (blockIdx.x / parts) * kBlock;
+    if (base >= n) return;  // block-uniform
+    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts);
+}
+
+
+}  // namespace rtx
+#endif
