@@ -171,7 +171,7 @@ BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, doub
 AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im, int index)
 {
     AffineShadowRec r = {im.a.x, im.a.y, im.a.z, im.b.x, im.b.y, im.b.z, im.c.x, im.c.y, im.c.z,
-                         s.center.x, s.center.y, s.center.z, -kInf, index, 0.0f, 0.0f};
+                         s.center.x, s.center.y, s.center.z, -kInf, index, kInf, kInf};
     if (im.d.x != 0 || im.d.y != 0 || im.d.z != 0) return r;
     double A[3][3] = {{im.a.x, im.a.y, im.a.z}, {im.b.x, im.b.y, im.b.z}, {im.c.x, im.c.y, im.c.z}};
     double n1 = 0, ninf = 0;
@@ -210,7 +210,8 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
     double R2 = rad * rad * (1.0 + 1.0 / 4096.0) + 1e-30;
     if (!(R2 < 1e37)) return r;
     r.neg_r2 = -up(R2);
-    r.pad0 = up(nA * nB * 1.001);  // >= cond(A): the packet test of the shadow kernel scales its cone by it
+    r.r_up = up(std::sqrt(R2) * 1.00001);          // what the packet test of the shadow kernel would compute per wave
+    r.fro_up = up(std::sqrt(fro2) * 1.00001);      // >= ||A||_2
     return r;
 }
 

@@ -162,6 +162,11 @@ __device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, co
 // with a = |w.C|, h^2 = |C|^2 - a^2, squared, every rounding pushed to the passing side.  Waves with an
 // abnormal lane, or a cone wider than ~70 degrees, do not use it (they take the grouped loop).
 // ------------------------------------------------------------------------------------------------
+// For BOUNDS only (never in an exact test): the hardware's 1-ulp square root and reciprocal instead of the
+// correctly rounded sequences (10+ instructions each); every use carries a relative margin of 1e-5 or more.
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
+
 struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; float c0; bool ok; };  // c0 = cos(theta), rounded down, before the widening by E
 
 __device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
@@ -222,7 +227,7 @@ __device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
     float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
     float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
     float h2 = (C2 - a * a) - 4e-6f * C2;              // rounded down (cancellation, |w| != 1)
-    float Rp = (sqrtf(-b.w) * 1.00001f + P.rho) * 1.00001f + 1e-20f;
+    float Rp = (fsqrt(-b.w) * 1.00001f + P.rho) * 1.00001f + 1e-20f;
     float rhs = Rp + a * P.sinT;
     return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // NaN (R = inf, never-bounded primitives) passes
 }
@@ -431,10 +436,10 @@ struct LexAcc {
     bool overflow;
 };
 
-// exact test of primitive k (per lane) with the order-independent update.  The primitive's 80-byte hot
-// record (SceneDev::phot) comes in with five independent loads: one memory round trip per round of the
-// lockstep loop, where sph_hot -> sph_xf -> sph_im was a chain of three.
-__device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
+// exact test of primitive k (per lane): 0 miss | 1 plain sphere | 2 triangle or polygon | 3 affine sphere, t set on a hit.
+// The primitive's 80-byte hot record (SceneDev::phot) comes in with five independent loads: one memory
+// round trip, where sph_hot -> sph_xf -> sph_im was a chain of three.
+__device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F3 nd, float& t)
 {
     const float4* p = S.phot + (size_t)k * 5;
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
@@ -449,35 +454,9 @@ __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, 
             to = inv_apply(o, im);
             td = normalized(inv_apply(d, im));
         }
-        float t;
-        if (sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t)) {
-            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
-            if (xf) {
-                if (t < kMaxT) {
-                    bool killed = false;
-#pragma unroll
-                    for (int e = 0; e < kAffList; e++) killed = killed || (h.ak[e] >= 0 && h.ak[e] < k && h.at[e] <= t);
-                    if (!killed) {
-                        bool placed = false;
-#pragma unroll
-                        for (int e = 0; e < kAffList; e++) {
-                            if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
-                            if (!placed && h.ak[e] < 0) { h.ak[e] = k; h.at[e] = t; placed = true; }
-                        }
-                        if (!placed) h.overflow = true;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < kAffList; e++)
-                    if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
-            }
-        }
+        return sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t) ? (xf ? 3 : 1) : 0;
     } else if (k >= S.ns + S.nt) {
-        float t;
-        if (polygon_test(o, d, q0, q1, S.poly_verts, t)) {
-            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
-        }
+        return polygon_test(o, d, q0, q1, S.poly_verts, t) ? 2 : 0;
     } else {
         TriRec T;
         T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
@@ -485,11 +464,42 @@ __device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, 
         T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
         T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
         T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
-        float t, vd;
-        if (triangle_test(o, d, T, t, vd)) {
-            if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
-        }
+        float vd;
+        return triangle_test(o, d, T, t, vd) ? 2 : 0;
     }
+}
+
+// the order-independent update of a ray's state with the hit (k, t) of kind 1 / 2 / 3 (see above)
+__device__ __forceinline__ void lex_update(LexAcc& h, int k, float t, int kind)
+{
+    if (t < h.nearest || (t == h.nearest && k < h.best)) { h.nearest = t; h.best = k; }
+    if (kind == 3) {
+        if (t < kMaxT) {
+            bool killed = false;
+#pragma unroll
+            for (int e = 0; e < kAffList; e++) killed = killed || (h.ak[e] >= 0 && h.ak[e] < k && h.at[e] <= t);
+            if (!killed) {
+                bool placed = false;
+#pragma unroll
+                for (int e = 0; e < kAffList; e++) {
+                    if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+                    if (!placed && h.ak[e] < 0) { h.ak[e] = k; h.at[e] = t; placed = true; }
+                }
+                if (!placed) h.overflow = true;
+            }
+        }
+    } else if (kind == 1) {
+#pragma unroll
+        for (int e = 0; e < kAffList; e++)
+            if (h.ak[e] >= 0 && k < h.ak[e] && t <= h.at[e]) h.ak[e] = -1;
+    }
+}
+
+__device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
+{
+    float t;
+    const int kind = exact_hit(S, k, o, d, nd, t);
+    if (kind) lex_update(h, k, t, kind);
 }
 
 __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int q, float4* tile, const int* perm,
@@ -633,6 +643,258 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pooled traversal (the per-ray traversal above with the WORK, not the rays, spread over the lanes).
+//
+// In closest_lanes a lane walks its own ray's clusters, groups and candidates, and every loop runs as long
+// as the wave's busiest lane needs: measured on the benchmark frame, 147 member steps per wave where the
+// average lane needs 40, each step a round trip of per-lane gathers.  Here a wave owns R rays (64, or 16 for
+// generations too small to fill the chip) whose data sit in LDS, and every stage is a list of independent
+// (ray, item) pairs in LDS that the 64 lanes consume 64 at a time, whoever the rays belong to:
+//   A  (ray, cluster sphere)          cone test                 64/R lanes per ray, kPoolQ clusters a round
+//   B  (ray, passing cluster)         its 8 sub-cluster spheres  8 lanes per pair   -> (ray, cluster, group)
+//   C  (ray, cluster, passing group)  its 8 members' filter      8 lanes per pair   -> (ray, primitive)
+//   D  (ray, primitive)               the exact test             1 lane per pair    -> hits
+//   E  hits are handed to the lane that owns the ray (one per ray per step) and folded into its LexAcc.
+// Loads are coalesced (8 lanes read 128 consecutive bytes), a list's addresses are known ahead so several
+// steps' loads are in flight together, and no lane idles while another works.  What is tested is what
+// closest_lanes tests -- the same cone tests on the same spheres, the same filter, every surviving
+// (ray, primitive) pair through the same exact test -- and LexAcc does not depend on the order of arrival,
+// except that affine-sphere clusters come first (phase 0 is drained before phase 1 starts).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPoolPrimBits = 26;  // (ray, primitive) entries: primitive | ray << 26 (rtx_context_create checks the scene fits)
+constexpr int kPoolB = 512;        // (ray, cluster) pairs of one round: R * clusters per round
+constexpr int kPoolC = 64 + 64;    // (ray, cluster, group) entries: fewer than 64 wait, one push adds up to 64
+constexpr int kPoolD = 64 + 64;    // (ray, primitive) entries: the same
+
+struct PoolLds {
+    float4 rayO[64];               // origin, w = flag bits (1 live, 2 abnormal)
+    float4 rayN[64];               // normalised direction
+    float4 rayD[64];               // direction as stored (the exact tests take both)
+    float4 csph[32];               // this round's cluster spheres { c, R }
+    int ccid[32];
+    unsigned short listB[kPoolB];  // ray << 5 | cluster slot of the round
+    unsigned int listC[kPoolC];    // cluster << 9 | ray << 3 | group
+    unsigned int listD[kPoolD];    // ray << 26 | primitive
+    int slot[64];                  // E: which lane delivers to ray r this step (-1 none)
+    int inK[64];                   // kind << 28 | primitive
+    float inT[64];
+};
+
+__device__ __forceinline__ void lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <int R>
+__device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W, const int* perm)
+{
+    constexpr int kPer = 64 / R;                                  // lanes per ray in stage A
+    constexpr int kPoolQ = (kPoolB / R < 32) ? kPoolB / R : 32;   // clusters per round
+    const int lane = threadIdx.x & 63;
+    const int myray = lane & (R - 1), part = lane / R;
+    // ---- the wave's rays: lanes < R own one each ----
+    const int q = q0 + lane;
+    const bool live = lane < R && q < n;
+    const int i = live ? (perm ? perm[q] : q) : 0;
+    F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
+    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    F3 nd = normalized(d);
+    const bool abn = live && ray_abnormal(o, d, nd, S.guard);
+    if (lane < R) {
+        W.rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
+        W.rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+        W.rayD[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+    W.slot[lane] = -1;
+    lds_fence();
+    const float4 aO = W.rayO[myray], aN = W.rayN[myray];  // stage A's ray of this lane
+    const F3 ao = f3(aO.x, aO.y, aO.z), an = f3(aN.x, aN.y, aN.z);
+    const bool alive = (__float_as_int(aO.w) & 1) != 0, aabn = (__float_as_int(aO.w) & 2) != 0;
+    LexAcc h;
+    h.nearest = kMaxT; h.best = -1; h.overflow = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
+    int nC = 0, nD = 0, tested = 0;
+
+    // E: hand the hits of a D step to the owners of their rays, one hit per ray per round
+    auto deliver = [&](bool pending, int rr, int k, float t, int kind) {
+        while (__any(pending)) {
+            if (pending) W.slot[rr] = lane;
+            lds_fence();
+            const bool win = pending && W.slot[rr] == lane;
+            if (win) { W.inK[rr] = k | (kind << 28); W.inT[rr] = t; pending = false; }
+            lds_fence();
+            if (lane < R && W.slot[lane] >= 0) {
+                const int e = W.inK[lane];
+                lex_update(h, e & ((1 << 28) - 1), W.inT[lane], e >> 28);
+                W.slot[lane] = -1;
+            }
+            lds_fence();
+        }
+    };
+    // D: exact tests of the last `cnt` (<= 64) list entries, one pair per lane
+    auto run_D = [&](int cnt) {
+        const int base = nD - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listD[base + (has ? lane : 0)];
+        const int k = (int)(e & ((1u << kPoolPrimBits) - 1u));
+        const int rr = (int)(e >> kPoolPrimBits);
+        const float4 rO = W.rayO[rr], rN = W.rayN[rr], rD = W.rayD[rr];
+        float t = 0.0f;
+        int kind = 0;
+        if (has) kind = exact_hit(S, k, f3(rO.x, rO.y, rO.z), f3(rD.x, rD.y, rD.z), f3(rN.x, rN.y, rN.z), t);
+        tested += cnt;
+        nD = base;
+        deliver(kind != 0, rr, k, t, kind);
+    };
+    // C: one (ray, cluster, group) per lane: its 8 members against the ray's filter
+    auto run_C = [&](int cnt) {
+        const int base = nC - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listC[base + (has ? lane : 0)];
+        const int rr = (int)((e >> 3) & 63u);
+        const size_t m = (size_t)(e >> 9) * 64 + (e & 7u) * 8;
+        float4 mb[kGroup];
+#pragma unroll
+        for (int v = 0; v < kGroup; v++) mb[v] = S.cmem[m + v];
+        const int4 k0 = *reinterpret_cast<const int4*>(S.cidx + m), k1 = *reinterpret_cast<const int4*>(S.cidx + m + 4);
+        const int kk[kGroup] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
+        const float4 rO = W.rayO[rr], rN = W.rayN[rr];
+        const bool use = (__float_as_int(rO.w) & 2) == 0;
+        const F3 fo = use ? f3(rO.x, rO.y, rO.z) : f3(1e18f, 0.0f, 0.0f);
+        const F3 fd = use ? f3(rN.x * kDirScale, rN.y * kDirScale, rN.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
+        nC = base;
+        unsigned pmask = 0u;
+#pragma unroll
+        for (int v = 0; v < kGroup; v++)
+            if (kk[v] >= 0 && (!use || !(filt(fo, fd, mb[v]) < 0.0f))) pmask |= 1u << v;
+        if (!has) pmask = 0u;
+        while (__any(pmask != 0u)) {  // one member per lane per push, a D step as soon as 64 pairs wait
+            const bool pass = pmask != 0u;
+            const int v = pass ? (__ffs(pmask) - 1) : 0;
+            pmask &= pmask - 1u;
+            int kv = kk[0];
+#pragma unroll
+            for (int j = 1; j < kGroup; j++) kv = (v == j) ? kk[j] : kv;
+            const unsigned long long bal = __ballot(pass);
+            if (pass) W.listD[nD + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)kv;
+            nD += __popcll(bal);
+            lds_fence();
+            if (nD >= 64) run_D(64);
+        }
+    };
+    // B: one (ray, cluster) per lane: its 8 sub-cluster spheres against the ray's cone
+    auto run_B = [&](int base, int cnt) {
+        const bool has = lane < cnt;
+        const unsigned e = W.listB[base + (has ? lane : 0)];
+        const int rr = (int)(e >> 5);
+        const int cid = W.ccid[e & 31u];
+        const float4* srec = S.csubR + (size_t)cid * 8;
+        float4 sb[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) sb[v] = srec[v];
+        const float4 rO = W.rayO[rr], rN = W.rayN[rr];
+        const bool rabn = (__float_as_int(rO.w) & 2) != 0;
+        const F3 ro = f3(rO.x, rO.y, rO.z), rn = f3(rN.x, rN.y, rN.z);
+        unsigned gmask = 0u;
+#pragma unroll
+        for (int v = 0; v < 8; v++)
+            if (rabn || !(cone_slack(ro, rn, sb[v]) < 0.0f)) gmask |= 1u << v;
+        if (!has) gmask = 0u;
+        while (__any(gmask != 0u)) {  // one group per lane per push, a C step as soon as 64 entries wait
+            const bool pass = gmask != 0u;
+            const int v = pass ? (__ffs(gmask) - 1) : 0;
+            gmask &= gmask - 1u;
+            const unsigned long long bal = __ballot(pass);
+            if (pass) W.listC[nC + lanes_below(bal)] = ((unsigned)cid << 9) | ((unsigned)rr << 3) | (unsigned)v;
+            nC += __popcll(bal);
+            lds_fence();
+            if (nC >= 64) run_C(64);
+        }
+    };
+
+    const int ncl = S.cseg[S.cnseg];
+    for (int phase = 0; phase < 2; phase++) {
+        const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
+        for (int cb = cbeg; cb < cend; cb += kPoolQ) {
+            const int ce = min(kPoolQ, cend - cb);
+            // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
+            if (lane < ce) {
+                const int c = S.corder[cb + lane];
+                W.ccid[lane] = c;
+                W.csph[lane] = S.cclR[c];
+            }
+            lds_fence();
+            unsigned cmask = 0u;
+            for (int u = part; u < ce; u += kPer) {
+                const float4 b = W.csph[u];
+                if (aabn || !(cone_slack(ao, an, b) < 0.0f)) cmask |= 1u << u;
+            }
+            if (!alive) cmask = 0u;
+            // the pairs that passed, as a list: a prefix sum over the lanes gives every lane its place
+            const int cnt = __popc(cmask);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            const int nB = __shfl(incl, 63);
+            {
+                int pos = incl - cnt;
+                while (cmask) {
+                    const int u = __ffs(cmask) - 1;
+                    cmask &= cmask - 1u;
+                    W.listB[pos++] = (unsigned short)((myray << 5) | u);
+                }
+            }
+            lds_fence();
+            for (int p0 = 0; p0 < nB; p0 += 64) run_B(p0, min(64, nB - p0));
+        }
+        // phase 0: every affine-sphere hit is known before the first plain sphere is tested
+        if (nC > 0) run_C(nC);
+        if (nD > 0) run_D(nD);
+    }
+    bool aliveList = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) aliveList = aliveList || h.ak[e] >= 0;
+    float nearest = h.nearest;
+    int best = h.best;
+    int tflag = (best >= 0 && best < S.ns && aliveList) ? kTFlag : 0;
+    const bool slow = live && h.overflow;
+    if (__any(slow)) {
+        const F3 fo = abn ? f3(1e18f, 0.0f, 0.0f) : o;
+        const F3 fd = abn ? f3(0.0f, 0.0f, 0.0f) : f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale);
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        const int nprim = S.ns + S.nt + S.np;
+        for (int k = 0; k < nprim; k++) {
+            const float4 b = S.bounds[k];
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
+        }
+        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+    }
+    if (S.pstat) {
+        const unsigned long long sl = __ballot(slow);
+        const unsigned long long ab = __ballot(abn);
+        if (lane == 0) {
+            atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, (unsigned long long)__popcll(sl) + ((unsigned long long)__popcll(ab) << 32));
+            atomicAdd(S.pstat + 3, (unsigned long long)tested);
+        }
+    }
+    if (live) {
+        L.t[i] = nearest;
+        L.prim[i] = (best < 0) ? -1 : (best | tflag);
+    }
+}
+
 // Thin generations (deep bounces: few, incoherent rays).  A workgroup takes only 64 rays and its
 // four waves split the primitive list into four contiguous slices, so a generation of a few
 // thousand rays still puts a wave on every SIMD and the serial walk per wave is 4x shorter.
@@ -735,9 +997,10 @@ constexpr size_t kPrefetchRays = (size_t)1 << 22;  // generation-0 frames below 
 
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
 {
+#ifdef RTX_LANES_OLD
     __shared__ float4 tile[kLaneLds * (kBlock / 64) / 16];  // the four waves' candidate lists and cluster queues (40 KiB)
     const int n = *nrays;
-    const int* pm = n > kThinRays ? perm : nullptr;
+    const int* pm = (perm && n > kThinRays) ? perm : nullptr;  // perm == nullptr: the host skipped the binning
     if (n <= kSplitClosest) {
         if (blockIdx.x * 64 >= n) return;  // block-uniform
         closest_lanes(S, L, n, blockIdx.x * 64 + (threadIdx.x >> 2), tile, pm, threadIdx.x & 3, 4);
@@ -745,6 +1008,19 @@ __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L
         if (blockIdx.x * kBlock >= n) return;
         closest_lanes(S, L, n, blockIdx.x * kBlock + threadIdx.x, tile, pm, 0, 1);
     }
+#else
+    __shared__ PoolLds pool[kBlock / 64];
+    const int n = *nrays;
+    const int* pm = (perm && n > kThinRays) ? perm : nullptr;  // perm == nullptr: the host skipped the binning
+    const int w = threadIdx.x >> 6;
+    if (n <= kSplitClosest) {
+        if (blockIdx.x * 64 >= n) return;  // block-uniform
+        closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w], pm);
+    } else {
+        if (blockIdx.x * kBlock >= n) return;
+        closest_pool<64>(S, L, n, blockIdx.x * kBlock + w * 64, pool[w], pm);
+    }
+#endif
 }
 
 

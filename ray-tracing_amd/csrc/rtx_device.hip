@@ -85,6 +85,11 @@ struct rtx_context {
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
     unsigned long long* d_pstat = nullptr;
+    // The previous frame's generation sizes, written by its last kernel into pinned host memory: [chunk][level],
+    // -1 = not known.  ONLY a hint for the launch plan (a generation expected to be thin skips the ray binning
+    // launches): every kernel reads the true count on the device, a stale or torn hint costs time, never pixels.
+    int* h_hint = nullptr;
+    int hint_chunks = 0;
     int* d_perm = nullptr; int* d_dummy = nullptr;
     // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
     // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream k % kSide with
@@ -146,6 +151,7 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
             return RTX_E_INVALID_ARG;
     }
     if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
+    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= ((int64_t)1 << kPoolPrimBits)) return RTX_E_TOO_LARGE;  // closest_pool's list entries
     if (sc->nlights > 65535) return RTX_E_TOO_LARGE;  // gridDim.y
     int nr = p->nranks <= 1 ? 1 : p->nranks;
     int rk = p->nranks <= 1 ? 0 : p->rank;
@@ -302,6 +308,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->dalloc(&c->d_tests, (size_t)8))) return rc;
     if ((rc = c->dalloc(&c->d_pstat, (size_t)8))) return rc;
     c->S.pstat = (params->flags & RTX_F_PACKET_STATS) ? c->d_pstat : nullptr;
+    c->S.dbg = getenv("RTX_DBG") ? atoi(getenv("RTX_DBG")) : 0;
 
     // chunking: level k holds at most fanout^k rays per level-0 ray
     const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
@@ -367,6 +374,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels))) return rc;
     }
+    c->hint_chunks = std::max(c->nframe_chunks, 1);
+    HIPCHK(hipHostMalloc((void**)&c->h_hint, sizeof(int) * (size_t)c->hint_chunks * levels, hipHostMallocDefault));
+    for (int j = 0; j < c->hint_chunks * levels; j++) c->h_hint[j] = -1;
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     for (int i = 0; i < std::min(levels, (int)rtx_context::kSide); i++) {
@@ -421,7 +431,10 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             unsigned g = grid_for(live_cap);
             const int* perm = nullptr;
-            if (k > 0 && !count && !exact_only) {
+            // the last frame's size of this generation (pinned memory, written by that frame's k_accumulate)
+            const int hint = (nchunks < c->hint_chunks) ? *(volatile const int*)(c->h_hint + (size_t)nchunks * levels + k) : -1;
+            const bool expect_thin = hint >= 0 && hint <= kThinRays - kThinRays / 8;  // k_closest_lanes does not use the binned order then
+            if (k > 0 && !count && !exact_only && !expect_thin) {
                 // bin the secondary rays by (origin cell, direction cell) so that waves are coherent packets
                 HIPCHK(hipMemsetAsync(c->r_hist, 0, sizeof(int) * (size_t)kRayBins, st));
                 hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->r_hist, c->r_rank);
@@ -435,7 +448,9 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
-            else if (k > 0) hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            else if (k > 0) {
+                hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            }
             else if (live_cap < kPrefetchRays) hipLaunchKernelGGL(k_closest_f<true>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             else hipLaunchKernelGGL(k_closest_f<false>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
@@ -487,7 +502,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
             hipLaunchKernelGGL(k_unwind, dim3(grid_for(bound[k])), dim3(kBlock), 0, st, c->S, Lk, Ln, nodes + k);
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels,
+                           c->h_hint + (size_t)std::min(nchunks, c->hint_chunks - 1) * levels);
     }
     if (nown > 0 && !(c->params.flags & RTX_F_NO_HALO))
         hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
@@ -532,6 +548,7 @@ void rtx_context_destroy(rtx_context* c)
         (void)hipSetDevice(c->device);
         if (c->rendered) (void)hipStreamSynchronize(c->last_stream);
         for (void* p : c->allocs) (void)hipFree(p);
+        if (c->h_hint) (void)hipHostFree(c->h_hint);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (auto e : c->kev) if (e) (void)hipEventDestroy(e);

@@ -38,8 +38,8 @@ BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard);
 
 // 64-byte filter record of one affine sphere for SHADOW rays (raytracing.cpp:571-576: the
 // direction is inverse-transformed, the origin is not): rows of the inverse's linear part, the
-// centre, -R^2 (inflated; -inf = always pass), the sphere's index and, in pad0, an upper bound of cond(A).
-struct AffineShadowRec { float ax, ay, az, bx, by, bz, cx, cy, cz, ox, oy, oz, neg_r2; int32_t index; float pad0, pad1; };
+// centre, -R^2 (inflated; -inf = always pass), the sphere's index, and for the shadow kernel's packet test R and ||A||_F, both rounded up.
+struct AffineShadowRec { float ax, ay, az, bx, by, bz, cx, cy, cz, ox, oy, oz, neg_r2; int32_t index; float r_up, fro_up; };
 AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im, int index);
 
 // Spatial clusters of up to 64 filter records each, for the two-level packet test (rtx_device.hip,

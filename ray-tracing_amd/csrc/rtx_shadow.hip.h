@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
 // sphere, (1 + 2^-13)(q.X)^2 >= |q|^2 (|X|^2 - R^2)  (rtx_bounds.cpp, affine_shadow_record).
 __device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, float4 m2, float4 m3)
 {
-    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index . .
+    // m0 = a.x a.y a.z b.x | m1 = b.y b.z c.x c.y | m2 = c.z o.x o.y o.z | m3 = -R^2 index R ||A||_F
     float qx = __builtin_fmaf(l.x, m0.x, __builtin_fmaf(l.y, m0.w, l.z * m1.z));
     float qy = __builtin_fmaf(l.x, m0.y, __builtin_fmaf(l.y, m1.x, l.z * m1.w));
     float qz = __builtin_fmaf(l.x, m0.z, __builtin_fmaf(l.y, m1.y, l.z * m2.x));
@@ -316,11 +316,12 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     const int k = S.sidx[m];
                     unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
                     pk_batches++; pk_surv += __popcll(mm);
+                    if (S.dbg & 4) mm = 0;
                     while (mm) {
                         const int u = __ffsll((long long)mm) - 1;
                         mm &= mm - 1;
                         const float4 br = bcast4(mb, u);
-                        if (!done && !(filt(fo, fd, br) < 0.0f)) {
+                        if (!done && !(filt(fo, fd, br) < 0.0f) && !(S.dbg & 2)) {
                             if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
                                 done = true;
                                 fo = f3(1e18f, 0.0f, 0.0f);
@@ -342,7 +343,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
             //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
             // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
-            if (!out && S.naff > 0) {
+            if (!out && S.naff > 0 && !(S.dbg & 1)) {
                 const F3 Lr = one_light ? apex : P.co;
                 const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
                 const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
@@ -364,17 +365,17 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
                         float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
                         float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
-                        const float qn = sqrtf(qx * qx + qy * qy + qz * qz);
-                        const float R = sqrtf(-m3.x) * 1.00001f;   // +inf for records that always pass, NaN never arises (m3.x <= 0)
-                        const float nF = sqrtf(m0.x * m0.x + m0.y * m0.y + m0.z * m0.z + m0.w * m0.w + m1.x * m1.x + m1.y * m1.y +
-                                               m1.z * m1.z + m1.w * m1.w + m2.x * m2.x) * 1.00001f;  // >= ||A||_2
+                        // bounds only: v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences, every
+                        // use below carries a 1e-5 .. 1e-4 relative margin
+                        const float qn = fsqrt(qx * qx + qy * qy + qz * qz);
+                        const float R = m3.z, nF = m3.w;           // sqrt(R^2) and ||A||_F, rounded up on the host; +inf: always pass
                         const float qlow = qn * 0.99999f - chord * nF;  // <= |ld A| for every ray of the block
                         if (qn < 1e18f && R < 1e18f && nF < 1e18f && qlow > 0.25f * qn && qlow > 1e-18f) {
-                            const float inv = 1.0f / qn;
+                            const float inv = frcp(qn);
                             qx *= inv; qy *= inv; qz *= inv;
                             // orthonormal pair around q (Duff et al.), good to ~1e-6
                             const float sg = (qz >= 0.0f) ? 1.0f : -1.0f;
-                            const float aa = -1.0f / (sg + qz);
+                            const float aa = -frcp(sg + qz);
                             const float bb = qx * qy * aa;
                             const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
                             const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
@@ -382,12 +383,13 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                             // |c - o| <= far for every ray of the block: o = Lr - D w + e
                             const F3 f1 = f3(E.x + Dmin * w.x, E.y + Dmin * w.y, E.z + Dmin * w.z);
                             const F3 f2 = f3(E.x + Dmax * w.x, E.y + Dmax * w.y, E.z + Dmax * w.z);
-                            const float far = sqrtf(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + rperp;
+                            const float far = fsqrt(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + rperp;
                             // a.(delta A) = delta.(A a^T): |.| <= chord |A a^T|; 1e-5 covers the pair's own orthogonality error
                             const F3 v1 = f3(m0.x * ax1.x + m0.y * ax1.y + m0.z * ax1.z, m0.w * ax1.x + m1.x * ax1.y + m1.y * ax1.z, m1.z * ax1.x + m1.w * ax1.y + m2.x * ax1.z);
                             const F3 v2 = f3(m0.x * ax2.x + m0.y * ax2.y + m0.z * ax2.z, m0.w * ax2.x + m1.x * ax2.y + m1.y * ax2.z, m1.z * ax2.x + m1.w * ax2.y + m2.x * ax2.z);
-                            const float g1 = (chord * sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) + 1e-5f * nF) / qlow;
-                            const float g2 = (chord * sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) + 1e-5f * nF) / qlow;
+                            const float iq = frcp(qlow) * 1.000001f;
+                            const float g1 = (chord * fsqrt(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) * 1.000001f + 1e-5f * nF) * iq;
+                            const float g2 = (chord * fsqrt(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) * 1.000001f + 1e-5f * nF) * iq;
                             const float base_T = (R + rperp + 0.0112f * far) * 1.0001f + 1e-5f * (far + Dfar);
                             const float T1 = base_T + g1 * far * 1.0001f, T2 = base_T + g2 * far * 1.0001f;
                             const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
@@ -398,6 +400,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         }
                     }
                     unsigned long long am = __ballot(pass);
+                    if (S.dbg & 8) am = 0;
                     pk_batches++; pk_aff += __popcll(am);
                     while (am) {
                         const int u = __ffsll((long long)am) - 1;

@@ -1,0 +1,12 @@
+"""Render the 4K benchmark frame twice (for counter passes)."""
+import sys, os, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rtxamd as rt
+p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
+rt.scenegen.write_c4(p)
+sc = rt.load_scene(p)
+ctx = rt.Context(sc, rt.Params.make(3840, 2160, 4))
+for _ in range(2):
+    ctx.render()
+print(ctx.stats().ms_total)
+ctx.close()
