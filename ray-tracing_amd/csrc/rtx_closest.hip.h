@@ -192,23 +192,23 @@ __device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, 
     float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
     P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
     float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
-    P.rho = wave_max(sqrtf(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
+    P.rho = wave_max(fsqrt(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
     if (apex_ok) {  // wave-uniform
         float ax = oo.x - apex.x, ay = oo.y - apex.y, az = oo.z - apex.z;
-        float maxD = wave_max(sqrtf(ax * ax + ay * ay + az * az));
+        float maxD = wave_max(fsqrt(ax * ax + ay * ay + az * az));
         float rho_apex = 1.3e-4f + 3.8e-3f * maxD;
         if (rho_apex < P.rho) { P.rho = rho_apex; P.co = apex; }
     }
     F3 sw = f3(wave_sum(dd.x), wave_sum(dd.y), wave_sum(dd.z));
-    float sn = sqrtf(sw.x * sw.x + sw.y * sw.y + sw.z * sw.z);
+    float sn = fsqrt(sw.x * sw.x + sw.y * sw.y + sw.z * sw.z);
     bad = bad || !(sn > 1e-3f) || !(P.rho < 1e30f);
-    float inv = 1.0f / fmaxf(sn, 1e-3f);
+    float inv = frcp(fmaxf(sn, 1e-3f));
     P.w = f3(sw.x * inv, sw.y * inv, sw.z * inv);
     float c = wave_min(P.w.x * dd.x + P.w.y * dd.y + P.w.z * dd.z) - 4e-6f;  // cos(theta), rounded down
     bad = bad || !(c > 0.35f);
     c = fminf(c, 1.0f);
     P.c0 = c;
-    float sT = sqrtf(fmaxf(0.0f, 1.0f - c * c)) + 4e-6f;
+    float sT = fsqrt(fmaxf(0.0f, 1.0f - c * c)) + 4e-6f;
     // widen by the filter's own angular tolerance (3.47e-3 rad) plus slack: E = 3.7e-3 rad
     const float cosE = 0.99999316f, sinE = 3.7e-3f;
     float cT = c * cosE - sT * sinE - 4e-6f;           // cos(theta + E), rounded down

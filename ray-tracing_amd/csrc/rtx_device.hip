@@ -308,7 +308,6 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->dalloc(&c->d_tests, (size_t)8))) return rc;
     if ((rc = c->dalloc(&c->d_pstat, (size_t)8))) return rc;
     c->S.pstat = (params->flags & RTX_F_PACKET_STATS) ? c->d_pstat : nullptr;
-    c->S.dbg = getenv("RTX_DBG") ? atoi(getenv("RTX_DBG")) : 0;
 
     // chunking: level k holds at most fanout^k rays per level-0 ray
     const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
@@ -485,6 +484,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)kSplitRays)) * kSplit));
+                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)kSplitRays8)) * 2 * kSplit));
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
                 hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }

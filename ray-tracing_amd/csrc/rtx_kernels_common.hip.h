@@ -31,7 +31,6 @@ struct SceneDev {
     const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
     int naff;
     F3 box_lo, box_inv;           // scene box for ray binning: cell = (o - box_lo) * box_inv, 16 cells per axis
-    int dbg;
     unsigned long long* pstat;    // [8] packet statistics: closest {waves, waves ok, batches, survivors}, shadow {same}
     const float4* sbounds;        // [nsb] filter records of the shadow casters except affine spheres (transposed scan of
     const int* sorder;            // [nsb]  unpacketable rays), and the primitive index of each

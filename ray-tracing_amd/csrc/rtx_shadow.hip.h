@@ -316,12 +316,11 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     const int k = S.sidx[m];
                     unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
                     pk_batches++; pk_surv += __popcll(mm);
-                    if (S.dbg & 4) mm = 0;
                     while (mm) {
                         const int u = __ffsll((long long)mm) - 1;
                         mm &= mm - 1;
                         const float4 br = bcast4(mb, u);
-                        if (!done && !(filt(fo, fd, br) < 0.0f) && !(S.dbg & 2)) {
+                        if (!done && !(filt(fo, fd, br) < 0.0f)) {
                             if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
                                 done = true;
                                 fo = f3(1e18f, 0.0f, 0.0f);
@@ -343,7 +342,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
             //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
             // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
-            if (!out && S.naff > 0 && !(S.dbg & 1)) {
+            if (!out && S.naff > 0) {
                 const F3 Lr = one_light ? apex : P.co;
                 const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
                 const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
@@ -351,9 +350,9 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 const float D = P.w.x * rel.x + P.w.y * rel.y + P.w.z * rel.z;
                 const F3 e = f3(D * P.w.x - rel.x, D * P.w.y - rel.y, D * P.w.z - rel.z);
                 const float Dmin = wave_min(D), Dmax = wave_max(D);
-                const float Dfar = wave_max(sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
-                const float rperp = wave_max(sqrtf(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
-                const float chord = sqrtf(fmaxf(0.0f, 2.0f - 2.0f * P.c0)) * 1.0001f + 2e-5f;  // |ld - w| over the block
+                const float Dfar = wave_max(fsqrt(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
+                const float rperp = wave_max(fsqrt(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
+                const float chord = fsqrt(fmaxf(0.0f, 2.0f - 2.0f * P.c0)) * 1.0001f + 2e-5f;  // |ld - w| over the block
                 for (int a0 = part * 64; a0 < S.naff && !out; a0 += 64 * parts) {
                     const int ai = min(a0 + lane, S.naff - 1);
                     const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
@@ -400,7 +399,6 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         }
                     }
                     unsigned long long am = __ballot(pass);
-                    if (S.dbg & 8) am = 0;
                     pk_batches++; pk_aff += __popcll(am);
                     while (am) {
                         const int u = __ffsll((long long)am) - 1;
@@ -465,11 +463,12 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
 // is kSplit times shorter.
 constexpr int kSplit = 4;
 constexpr int kSplitRays = 1 << 21;
+constexpr int kSplitRays8 = 1 << 19;  // ... and by 2 * kSplit workgroups below this
 
 __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
 {
     const int n = *cnt_in;
-    const int parts = (n <= kSplitRays) ? kSplit : 1;
+    const int parts = (n <= kSplitRays8) ? 2 * kSplit : (n <= kSplitRays) ? kSplit : 1;
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
     shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts);
