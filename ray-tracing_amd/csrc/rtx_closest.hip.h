@@ -808,11 +808,12 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         for (int v = 0; v < 8; v++)
             if (rabn || !(cone_slack(ro, rn, sb[v]) < 0.0f)) gmask |= 1u << v;
         if (!has) gmask = 0u;
-        while (__any(gmask != 0u)) {  // one group per lane per push, a C step as soon as 64 entries wait
-            const bool pass = gmask != 0u;
-            const int v = pass ? (__ffs(gmask) - 1) : 0;
-            gmask &= gmask - 1u;
+        // pushes in GROUP order (the lanes are already in cluster order): the 64 entries of a C step then name
+        // few distinct groups, whose members neighbouring lanes read together; a C step as soon as 64 entries wait
+        for (int v = 0; v < 8; v++) {
+            const bool pass = (gmask >> v) & 1u;
             const unsigned long long bal = __ballot(pass);
+            if (bal == 0ull) continue;  // wave-uniform
             if (pass) W.listC[nC + lanes_below(bal)] = ((unsigned)cid << 9) | ((unsigned)rr << 3) | (unsigned)v;
             nC += __popcll(bal);
             lds_fence();
@@ -838,22 +839,14 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
                 if (aabn || !(cone_slack(ao, an, b) < 0.0f)) cmask |= 1u << u;
             }
             if (!alive) cmask = 0u;
-            // the pairs that passed, as a list: a prefix sum over the lanes gives every lane its place
-            const int cnt = __popc(cmask);
-            int incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off);
-                if (lane >= off) incl += up;
-            }
-            const int nB = __shfl(incl, 63);
-            {
-                int pos = incl - cnt;
-                while (cmask) {
-                    const int u = __ffs(cmask) - 1;
-                    cmask &= cmask - 1u;
-                    W.listB[pos++] = (unsigned short)((myray << 5) | u);
-                }
+            // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
+            // cluster's sub-spheres (one cache line for the lot, where a list in ray order touches 64)
+            int nB = 0;
+            for (int u = 0; u < ce; u++) {
+                const bool bit = (cmask >> u) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 5) | u);
+                nB += __popcll(bal);
             }
             lds_fence();
             for (int p0 = 0; p0 < nB; p0 += 64) run_B(p0, min(64, nB - p0));
