@@ -776,15 +776,13 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         for (int v = 0; v < kGroup; v++)
             if (kk[v] >= 0 && (!use || !(filt(fo, fd, mb[v]) < 0.0f))) pmask |= 1u << v;
         if (!has) pmask = 0u;
-        while (__any(pmask != 0u)) {  // one member per lane per push, a D step as soon as 64 pairs wait
-            const bool pass = pmask != 0u;
-            const int v = pass ? (__ffs(pmask) - 1) : 0;
-            pmask &= pmask - 1u;
-            int kv = kk[0];
+        // pushes in MEMBER order: neighbouring lanes (rays of one group) that pass the same member sit together in D
 #pragma unroll
-            for (int j = 1; j < kGroup; j++) kv = (v == j) ? kk[j] : kv;
+        for (int v = 0; v < kGroup; v++) {
+            const bool pass = (pmask >> v) & 1u;
             const unsigned long long bal = __ballot(pass);
-            if (pass) W.listD[nD + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)kv;
+            if (bal == 0ull) continue;  // wave-uniform
+            if (pass) W.listD[nD + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)kk[v];
             nD += __popcll(bal);
             lds_fence();
             if (nD >= 64) run_D(64);
