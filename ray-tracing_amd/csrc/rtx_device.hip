@@ -288,6 +288,39 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.box_lo = {lo[0], lo[1], lo[2]};
             c->S.box_inv = {inv[0], inv[1], inv[2]};
         }
+        c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
+        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0) {
+            // (light, direction cell) -> affine spheres table for the shadow passes (k_affine_cells)
+            const int words = (c->S.naff + 63) / 64;
+            int G = 256;
+            while ((size_t)c->S.nl * G * G * words * 8 > ((size_t)256 << 20) && G > 16) G /= 2;
+            if ((size_t)c->S.nl * G * G * words * 8 <= ((size_t)256 << 20)) {
+                // the table covers origins up to the far corner of the scene box (rays from further away, possible
+                // only through the reference's odd hit points on affine spheres, make their wave test every sphere)
+                std::vector<float> dt(c->S.nl);
+                for (int l = 0; l < c->S.nl; l++) {
+                    double far2 = 0;
+                    const float lp[3] = {P.lights[l].point.x, P.lights[l].point.y, P.lights[l].point.z};
+                    const float lo[3] = {c->S.box_lo.x, c->S.box_lo.y, c->S.box_lo.z};
+                    const float inv[3] = {c->S.box_inv.x, c->S.box_inv.y, c->S.box_inv.z};
+                    for (int a = 0; a < 3; a++) {
+                        const double hi = (double)lo[a] + 16.0 / (double)inv[a];
+                        const double d = std::max(std::fabs((double)lp[a] - lo[a]), std::fabs((double)lp[a] - hi));
+                        far2 += d * d;
+                    }
+                    const double v = std::sqrt(far2) * 1.01 + 1.0;
+                    dt[l] = std::isfinite(v) ? (float)v : 0.0f;
+                }
+                float* d_dt = nullptr; unsigned long long* tab = nullptr;
+                if ((rc = c->upload(&d_dt, dt))) return rc;
+                if ((rc = c->dalloc(&tab, (size_t)c->S.nl * G * G * words))) return rc;
+                const int ncell = c->S.nl * G * G;
+                hipLaunchKernelGGL(k_affine_cells, dim3((unsigned)((ncell + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, 0, c->S, G, d_dt, tab, words);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipDeviceSynchronize());
+                c->S.aff_cells = tab; c->S.aff_dt = d_dt; c->S.aff_words = words; c->S.aff_G = G;
+            }
+        }
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
         if ((rc = c->upload(&iy, P.imagey))) return rc;

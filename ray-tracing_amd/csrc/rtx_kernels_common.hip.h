@@ -29,6 +29,9 @@ struct SceneDev {
     F3 ambient;
     const float4* bounds;         // [ns+nt] filter records { c, -R^2 } (rtx_bounds.cpp)
     const float4* aff_shadow;     // [naff*4] AffineShadowRec: affine spheres for shadow rays
+    const unsigned long long* aff_cells;  // [nl*G*G][aff_words] per (light, direction cell): which affine spheres a shadow ray of that cell can pass (nullptr: no table)
+    const float* aff_dt;          // [nl] the table covers origins within this distance of the light
+    int aff_words, aff_G;
     int naff;
     F3 box_lo, box_inv;           // scene box for ray binning: cell = (o - box_lo) * box_inv, 16 cells per axis
     unsigned long long* pstat;    // [8] packet statistics: closest {waves, waves ok, batches, survivors}, shadow {same}

@@ -248,9 +248,110 @@ __device__ __forceinline__ float filt_affine(F3 o, F3 l, float4 m0, float4 m1, f
     return __builtin_fmaf(bq * (1.0f + 1.0f / 8192.0f), bq, -(qq * cc));
 }
 
+// The affine strip test (derivation in shadow_pass_packet): can the affine sphere m0..m3 pass the per-ray filter of
+// ANY ray whose origin is K.Lr - D K.w + e, D in [K.Dmin, K.Dmax], |e| <= K.rperp, |K.Lr - o| <= K.Dfar, and whose
+// direction is within the chord K.chord of K.w?  false = no such ray.
+struct StripPacket { F3 w, Lr; float chord, Dmin, Dmax, Dfar, rperp; };
+
+__device__ __forceinline__ bool affine_strip_pass(const StripPacket& K, float4 m0, float4 m1, float4 m2, float4 m3)
+{
+    const F3 w = K.w;
+    // rows of A: ra = (m0.x m0.y m0.z), rb = (m0.w m1.x m1.y), rc = (m1.z m1.w m2.x); q = w A
+    float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
+    float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
+    float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
+    // bounds only: v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences, every
+    // use below carries a 1e-5 .. 1e-4 relative margin
+    const float qn = fsqrt(qx * qx + qy * qy + qz * qz);
+    const float R = m3.z, nF = m3.w;           // sqrt(R^2) and ||A||_F, rounded up on the host; +inf: always pass
+    const float qlow = qn * 0.99999f - K.chord * nF;  // <= |ld A| for every ray of the block
+    if (qn < 1e18f && R < 1e18f && nF < 1e18f && qlow > 0.25f * qn && qlow > 1e-18f) {
+        const float inv = frcp(qn);
+        qx *= inv; qy *= inv; qz *= inv;
+        // orthonormal pair around q (Duff et al.), good to ~1e-6
+        const float sg = (qz >= 0.0f) ? 1.0f : -1.0f;
+        const float aa = -frcp(sg + qz);
+        const float bb = qx * qy * aa;
+        const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
+        const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
+        const F3 E = f3(m2.y - K.Lr.x, m2.z - K.Lr.y, m2.w - K.Lr.z);
+        // |c - o| <= far for every ray of the block: o = Lr - D w + e
+        const F3 f1 = f3(E.x + K.Dmin * w.x, E.y + K.Dmin * w.y, E.z + K.Dmin * w.z);
+        const F3 f2 = f3(E.x + K.Dmax * w.x, E.y + K.Dmax * w.y, E.z + K.Dmax * w.z);
+        const float far = fsqrt(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + K.rperp;
+        // a.(delta A) = delta.(A a^T): |.| <= K.chord |A a^T|; 1e-5 covers the pair's own orthogonality error
+        const F3 v1 = f3(m0.x * ax1.x + m0.y * ax1.y + m0.z * ax1.z, m0.w * ax1.x + m1.x * ax1.y + m1.y * ax1.z, m1.z * ax1.x + m1.w * ax1.y + m2.x * ax1.z);
+        const F3 v2 = f3(m0.x * ax2.x + m0.y * ax2.y + m0.z * ax2.z, m0.w * ax2.x + m1.x * ax2.y + m1.y * ax2.z, m1.z * ax2.x + m1.w * ax2.y + m2.x * ax2.z);
+        const float iq = frcp(qlow) * 1.000001f;
+        const float g1 = (K.chord * fsqrt(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) * 1.000001f + 1e-5f * nF) * iq;
+        const float g2 = (K.chord * fsqrt(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) * 1.000001f + 1e-5f * nF) * iq;
+        const float base_T = (R + K.rperp + 0.0112f * far) * 1.0001f + 1e-5f * (far + K.Dfar);
+        const float T1 = base_T + g1 * far * 1.0001f, T2 = base_T + g2 * far * 1.0001f;
+        const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
+        const float t2 = ax2.x * w.x + ax2.y * w.y + ax2.z * w.z, e2 = ax2.x * E.x + ax2.y * E.y + ax2.z * E.z;
+        const float lo1 = fminf(-K.Dmin * t1, -K.Dmax * t1), hi1 = fmaxf(-K.Dmin * t1, -K.Dmax * t1);
+        const float lo2 = fminf(-K.Dmin * t2, -K.Dmax * t2), hi2 = fmaxf(-K.Dmin * t2, -K.Dmax * t2);
+        if (e1 < lo1 - T1 || e1 > hi1 + T1 || e2 < lo2 - T2 || e2 > hi2 + T2) return false;
+    }
+    return true;
+}
+
+// The affine spheres a shadow ray towards light li with its direction in cell m of the G x G octahedral map
+// (light_cell) can pass, as a bit mask per (light, cell): the strip test above with the CELL as the packet.
+//   * directions: decode(q) = (qx, qy, 1 - |qx| - |qy|) (folded for z < 0) moves by at most sqrt(6) |dq|_max,
+//     its L1 norm is 1 so its length is >= 1/sqrt(3), and normalising divides by that: every unit direction of
+//     the cell is within 3 sqrt(2) / G of the centre's (half a cell is |dq|_max = 1/G); 1e-5 covers the rounding
+//     of light_cell at the cell borders.
+//   * origins: o = L - D w + e with 0 <= D <= |L - o| <= dt[li] (checked per wave by the pass) and
+//     |e| <= |L - o| sin(angle(L - o, w)) <= dt (chord + bias / |L - o|): the line to the light leaves from the
+//     hit point, the ray from a point 1e-4 off it (raytracing.cpp:568).
+// Built once per context; the pass ORs the masks of the cells its rays fall into and runs the strip test of its
+// own, tighter packet on those spheres only.
+__device__ __forceinline__ unsigned demorton8(unsigned x)
+{
+    x &= 0x5555u;
+    x = (x | (x >> 1)) & 0x3333u;
+    x = (x | (x >> 2)) & 0x0f0fu;
+    x = (x | (x >> 4)) & 0x00ffu;
+    return x;
+}
+
+__global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, const float* dt, unsigned long long* table, int words)
+{
+    const int cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);  // one wave per (light, cell)
+    const int lane = threadIdx.x & 63;
+    if (cell >= S.nl * G * G) return;
+    const int li = cell / (G * G), m = cell % (G * G);
+    const float qx = ((float)demorton8((unsigned)m) + 0.5f) / (float)G * 2.0f - 1.0f;
+    const float qy = ((float)demorton8((unsigned)m >> 1) + 0.5f) / (float)G * 2.0f - 1.0f;
+    F3 v;
+    if (fabsf(qx) + fabsf(qy) <= 1.0f) v = f3(qx, qy, 1.0f - fabsf(qx) - fabsf(qy));
+    else v = f3((1.0f - fabsf(qy)) * (qx >= 0.0f ? 1.0f : -1.0f), (1.0f - fabsf(qx)) * (qy >= 0.0f ? 1.0f : -1.0f), 1.0f - fabsf(qx) - fabsf(qy));
+    const float vn = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    StripPacket K;
+    K.w = f3(v.x / vn, v.y / vn, v.z / vn);
+    K.Lr = f3(S.lights[li].point);
+    K.chord = 4.2427f / (float)G + 1e-5f;
+    const float D = dt[li];
+    K.Dmin = -1e-3f;
+    K.Dmax = D * 1.001f + 1e-3f;
+    K.Dfar = D * 1.001f + 1e-3f;
+    K.rperp = D * K.chord * 1.01f + 3e-4f;
+    for (int a0 = 0; a0 < S.naff; a0 += 64) {
+        const int ai = min(a0 + lane, S.naff - 1);
+        const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+        const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+        const unsigned long long bal = __ballot(a0 + lane < S.naff && affine_strip_pass(K, m0, m1, m2, m3));
+        if (lane == 0) table[(size_t)cell * words + (a0 >> 6)] = bal;
+    }
+}
+
+constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: every affine sphere is tested
+
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
-                                                   unsigned char* lit, const int lit_cap, const int part, const int parts)
+                                                   unsigned char* lit, const int lit_cap, const int part, const int parts,
+                                                   unsigned short* alist)
 {
     const int c0 = 0, c1 = S.nsb;
     const int lane = threadIdx.x & 63;
@@ -281,6 +382,51 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     // traced as a packet of its own with the other lanes switched off.  A single ray that makes no packet
     // (an abnormal one) takes the transposed scan below.
     const int li = id / lit_cap;
+    // The wave's affine candidates: the union of the table's masks over the (light, cell)s of its rays, as a list.
+    // Any ray the table does not cover (too far from its light), or a list that does not fit: every affine sphere.
+    int nlist = S.naff;
+    bool listed = false;
+    if (S.aff_cells != nullptr && S.naff > 0) {
+        bool covered = true;
+        int key = -1;
+        if (live && !abn) {  // abnormal rays take the transposed scan over everything below
+            const F3 Lp = f3(S.lights[li].point);
+            const float lx = Lp.x - o.x, ly = Lp.y - o.y, lz = Lp.z - o.z;
+            const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
+            covered = dist <= S.aff_dt[li] && dist >= 1e-2f;
+            key = li * S.aff_G * S.aff_G + light_cell(ld, S.aff_G);
+        }
+        if (__all(covered)) {
+            unsigned long long acc = 0ull;
+            unsigned long long pending = __ballot(key >= 0);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const int k0 = __shfl(key, leader);
+                pending &= ~__ballot(key == k0);
+                if (lane < S.aff_words) acc |= S.aff_cells[(size_t)k0 * S.aff_words + lane];
+            }
+            const int cnt = __popcll(acc);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            const int total = __shfl(incl, 63);
+            if (total <= kAffListCap) {
+                int pos = incl - cnt;
+                while (acc) {
+                    const int b = __ffsll((long long)acc) - 1;
+                    acc &= acc - 1ull;
+                    alist[pos++] = (unsigned short)(lane * 64 + b);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                nlist = total;
+                listed = true;
+            }
+        }
+    }
     unsigned long long remaining = __ballot(live), fallback = 0ull;
     int size = 64;
     while (remaining) {
@@ -353,51 +499,15 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 const float Dfar = wave_max(fsqrt(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z)) * 1.00001f;
                 const float rperp = wave_max(fsqrt(e.x * e.x + e.y * e.y + e.z * e.z)) * 1.0001f + 1e-5f * Dfar;
                 const float chord = fsqrt(fmaxf(0.0f, 2.0f - 2.0f * P.c0)) * 1.0001f + 2e-5f;  // |ld - w| over the block
-                for (int a0 = part * 64; a0 < S.naff && !out; a0 += 64 * parts) {
-                    const int ai = min(a0 + lane, S.naff - 1);
+                StripPacket K;
+                K.w = P.w; K.Lr = Lr; K.chord = chord; K.Dmin = Dmin; K.Dmax = Dmax; K.Dfar = Dfar; K.rperp = rperp;
+                for (int a0 = part * 64; a0 < nlist && !out; a0 += 64 * parts) {
+                    const int aj = min(a0 + lane, nlist - 1);
+                    const int ai = listed ? (int)alist[aj] : aj;
                     const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
                     const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
-                    bool pass = a0 + lane < S.naff;
-                    {
-                        const F3 w = P.w;
-                        // rows of A: ra = (m0.x m0.y m0.z), rb = (m0.w m1.x m1.y), rc = (m1.z m1.w m2.x); q = w A
-                        float qx = w.x * m0.x + w.y * m0.w + w.z * m1.z;
-                        float qy = w.x * m0.y + w.y * m1.x + w.z * m1.w;
-                        float qz = w.x * m0.z + w.y * m1.y + w.z * m2.x;
-                        // bounds only: v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences, every
-                        // use below carries a 1e-5 .. 1e-4 relative margin
-                        const float qn = fsqrt(qx * qx + qy * qy + qz * qz);
-                        const float R = m3.z, nF = m3.w;           // sqrt(R^2) and ||A||_F, rounded up on the host; +inf: always pass
-                        const float qlow = qn * 0.99999f - chord * nF;  // <= |ld A| for every ray of the block
-                        if (qn < 1e18f && R < 1e18f && nF < 1e18f && qlow > 0.25f * qn && qlow > 1e-18f) {
-                            const float inv = frcp(qn);
-                            qx *= inv; qy *= inv; qz *= inv;
-                            // orthonormal pair around q (Duff et al.), good to ~1e-6
-                            const float sg = (qz >= 0.0f) ? 1.0f : -1.0f;
-                            const float aa = -frcp(sg + qz);
-                            const float bb = qx * qy * aa;
-                            const F3 ax1 = f3(1.0f + sg * qx * qx * aa, sg * bb, -sg * qx);
-                            const F3 ax2 = f3(bb, sg + qy * qy * aa, -qy);
-                            const F3 E = f3(m2.y - Lr.x, m2.z - Lr.y, m2.w - Lr.z);
-                            // |c - o| <= far for every ray of the block: o = Lr - D w + e
-                            const F3 f1 = f3(E.x + Dmin * w.x, E.y + Dmin * w.y, E.z + Dmin * w.z);
-                            const F3 f2 = f3(E.x + Dmax * w.x, E.y + Dmax * w.y, E.z + Dmax * w.z);
-                            const float far = fsqrt(fmaxf(f1.x * f1.x + f1.y * f1.y + f1.z * f1.z, f2.x * f2.x + f2.y * f2.y + f2.z * f2.z)) * 1.0001f + rperp;
-                            // a.(delta A) = delta.(A a^T): |.| <= chord |A a^T|; 1e-5 covers the pair's own orthogonality error
-                            const F3 v1 = f3(m0.x * ax1.x + m0.y * ax1.y + m0.z * ax1.z, m0.w * ax1.x + m1.x * ax1.y + m1.y * ax1.z, m1.z * ax1.x + m1.w * ax1.y + m2.x * ax1.z);
-                            const F3 v2 = f3(m0.x * ax2.x + m0.y * ax2.y + m0.z * ax2.z, m0.w * ax2.x + m1.x * ax2.y + m1.y * ax2.z, m1.z * ax2.x + m1.w * ax2.y + m2.x * ax2.z);
-                            const float iq = frcp(qlow) * 1.000001f;
-                            const float g1 = (chord * fsqrt(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) * 1.000001f + 1e-5f * nF) * iq;
-                            const float g2 = (chord * fsqrt(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z) * 1.000001f + 1e-5f * nF) * iq;
-                            const float base_T = (R + rperp + 0.0112f * far) * 1.0001f + 1e-5f * (far + Dfar);
-                            const float T1 = base_T + g1 * far * 1.0001f, T2 = base_T + g2 * far * 1.0001f;
-                            const float t1 = ax1.x * w.x + ax1.y * w.y + ax1.z * w.z, e1 = ax1.x * E.x + ax1.y * E.y + ax1.z * E.z;
-                            const float t2 = ax2.x * w.x + ax2.y * w.y + ax2.z * w.z, e2 = ax2.x * E.x + ax2.y * E.y + ax2.z * E.z;
-                            const float lo1 = fminf(-Dmin * t1, -Dmax * t1), hi1 = fmaxf(-Dmin * t1, -Dmax * t1);
-                            const float lo2 = fminf(-Dmin * t2, -Dmax * t2), hi2 = fmaxf(-Dmin * t2, -Dmax * t2);
-                            if (e1 < lo1 - T1 || e1 > hi1 + T1 || e2 < lo2 - T2 || e2 > hi2 + T2) pass = false;
-                        }
-                    }
+                    bool pass = a0 + lane < nlist;
+                    if (pass) pass = affine_strip_pass(K, m0, m1, m2, m3);
                     unsigned long long am = __ballot(pass);
                     pk_batches++; pk_aff += __popcll(am);
                     while (am) {
@@ -469,9 +579,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
 {
     const int n = *cnt_in;
     const int parts = (n <= kSplitRays8) ? 2 * kSplit : (n <= kSplitRays) ? kSplit : 1;
+    __shared__ unsigned short alist[kBlock / 64][kAffListCap];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
-    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts);
+    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6]);
 }
 
 

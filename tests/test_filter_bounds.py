@@ -204,3 +204,34 @@ def test_affine_shadow_filter(rt, oracle, tmp_path):
         P = affine_shadow_pass(rec, o, d)
         assert acc.sum() > 50
         assert not (acc & ~P).any()
+
+
+def test_direction_cell_chord_bound():
+    """k_affine_cells (rtx_shadow.hip.h) takes every unit direction of a cell of the G x G octahedral map to lie within
+    3 sqrt(2) / G of the direction of the cell's centre.  Checked here on a numpy restatement of light_cell and of
+    the kernel's decode, on random directions and on directions pushed onto cell borders and folds."""
+    rng = np.random.default_rng(7)
+    for G in (16, 64, 256):
+        d = rng.normal(size=(200000, 3)).astype(np.float32)
+        # a share of the samples on the octahedron's folds and on axis planes
+        d[:20000, 2] = 0.0
+        d[20000:40000, 0] = 0.0
+        d[40000:60000, 2] *= 1e-4
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        s = np.abs(d).sum(axis=1)
+        px, py = d[:, 0] / s, d[:, 1] / s
+        neg = d[:, 2] < 0
+        qx = np.where(neg, (1 - np.abs(py)) * np.where(px >= 0, 1.0, -1.0), px)
+        qy = np.where(neg, (1 - np.abs(px)) * np.where(py >= 0, 1.0, -1.0), py)
+        cx = np.clip(np.floor((qx * 0.5 + 0.5) * G), 0, G - 1)
+        cy = np.clip(np.floor((qy * 0.5 + 0.5) * G), 0, G - 1)
+        # the kernel's decode of the cell centre
+        ux, uy = (cx + 0.5) / G * 2 - 1, (cy + 0.5) / G * 2 - 1
+        inner = np.abs(ux) + np.abs(uy) <= 1
+        vx = np.where(inner, ux, (1 - np.abs(uy)) * np.where(ux >= 0, 1.0, -1.0))
+        vy = np.where(inner, uy, (1 - np.abs(ux)) * np.where(uy >= 0, 1.0, -1.0))
+        vz = 1 - np.abs(ux) - np.abs(uy)
+        v = np.stack([vx, vy, vz], axis=1)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        chord = np.linalg.norm(d.astype(np.float64) - v, axis=1)
+        assert chord.max() <= 4.2427 / G + 1e-5, (G, chord.max() * G)

@@ -4,7 +4,7 @@ import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
-for md in (1,):
+for md in (0, 4):
     ctx = rt.Context(sc, rt.Params.make(3840, 2160, md, flags=rt.host.F_TIME_KERNELS))
     for _ in range(4): ctx.render()
     st = ctx.stats()

@@ -9,8 +9,6 @@ for md in (0, 4):
     ctx.render(); ctx.render()
     st = ctx.stats()
     ps = list(st.packet_stats)
-    w = ps[4] & 0xffffffff
-    print("depth %d: sampled shadow waves %d; per wave: batches %.1f survivors %.1f affine survivors %.1f exact runs %.1f affine exact runs %.1f lanes per exact run %.1f fallback rays %.3f" % (
-        md, w, (ps[4] >> 32) / w, (ps[5] & 0xffffffff) / w, (ps[5] >> 32) / w, (ps[6] & 0xffffffff) / w, (ps[6] >> 32) / w,
-        (ps[7] & ((1 << 40) - 1)) / max(1, (ps[6] & 0xffffffff) + (ps[6] >> 32)), (ps[7] >> 40) / w))
+    w = ps[4] & 0xffffff
+    print("depth %d: shadow waves %d listed %d avg list %.1f | batches/wave %.1f aff survivors/wave %.2f" % (md, w, (ps[4] >> 24) & 0xffff, (ps[4] >> 40) / w, ps[6] / w, (ps[7] >> 32) / w))
     ctx.close()
