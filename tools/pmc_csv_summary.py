@@ -7,7 +7,8 @@ for path in sys.argv[1:]:
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r["Kernel_Name"].split("(")[0]
-            if not k.startswith("rtx::"): continue
+            if "rtx::" not in k: continue
+            k = k.replace("void ", "")
             d = agg.setdefault(k, {"dispatches": set(), "vgpr": r["VGPR_Count"], "lds": r["LDS_Block_Size"]})
             d["dispatches"].add((path, r["Dispatch_Id"]))
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
