@@ -251,13 +251,12 @@ __device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
 }
 
 template <bool PREFETCH>
-__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, const int* perm)
+__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
 {
     const int lane = threadIdx.x & 63;
     const int q = base + threadIdx.x;
     const bool live = q < n;
-    // secondary generations are traced in binned order (k_ray_bin): perm maps sorted position -> ray slot
-    const int i = live ? (perm ? perm[q] : q) : 0;
+    const int i = live ? q : 0;
     const int ii = i;
     F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
     F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
@@ -402,18 +401,11 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
 }
 
 
-// Per-ray traversal of the cluster hierarchy, for the generations after the first: reflection and
-// refraction rays of neighbouring pixels leave curved surfaces in all directions, a wave of them is no
-// packet (measured on the benchmark scene: the packet test kept 1,171 of 10,000 primitives per wave at
-// level 1, against 17 at level 0).  Every LANE walks the hierarchy for its own ray instead:
-//   1. the filter against every cluster sphere (wave-uniform loop, 64 clusters per round, a bit per pass),
-//   2. lanes step through their own passing clusters in lockstep and run the filter against the 64
-//      members (per-lane gathers, sign bits AND-ed over groups of 8); members that pass are appended to
-//      the lane's candidate list in LDS,
-//   3. whenever a list is nearly full, and at the end, all lanes run the exact tests of their lists in
-//      lockstep.
-// The candidates of a ray arrive in cluster order, not file order, so the reference's sequential scan
-// (:385-418) is restated order-independently.  With H = the accepted hits (t_k, k):
+// Closest hit for the generations after the first: reflection and refraction rays of neighbouring pixels
+// leave curved surfaces in all directions, a wave of them is no packet (measured on the benchmark scene: the
+// packet test kept 1,171 of 10,000 primitives per wave at level 1, against 17 at level 0), so every RAY walks
+// the cluster hierarchy (closest_pool below).  Its candidates arrive in cluster order, not file order, so the
+// reference's sequential scan (:385-418) is restated order-independently.  With H = the accepted hits (t_k, k):
 //   * nearest/best = the lexicographic minimum of (t_k, k) over hits with t_k < Max_t: the scan keeps
 //     the first of equal t's because it updates on strict `<` only;
 //   * a triangle that wins resets the `transformed` flag and only triangles follow it, so the flag is
@@ -421,14 +413,10 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
 //     reached it: t_k < Max_t and t_j > t_k for every hit j < k.  Affine-sphere clusters are traversed
 //     FIRST; their hits form a list in which (j < k, t_j <= t_k) removes k, and every later hit of a
 //     plain sphere removes entries the same way.  The flag is "list not empty".  The list holds the
-//     staircase of affine hits (index up, t down), 4 entries; a fifth sends the lane to the ordered
+//     staircase of affine hits (index up, t down), 4 entries; a fifth sends the ray to the ordered
 //     scan over every primitive at the end (wave-uniform loop, only the flagged lanes active).
 // Rays the filter does not cover (ray_abnormal) take every cluster and every member.
-constexpr int kCandCap = 24;   // candidate list entries per lane (LDS)
-constexpr int kQBatch = 32;    // clusters per round; the lane's queue of passing clusters holds as many
 constexpr int kAffList = 4;
-
-constexpr int kLaneLds = kCandCap * 64 * 4 + kQBatch * 64 * 2;  // LDS bytes per wave: candidate lists + cluster queues
 
 struct LexAcc {
     float nearest; int best;
@@ -495,160 +483,12 @@ __device__ __forceinline__ void lex_update(LexAcc& h, int k, float t, int kind)
     }
 }
 
-__device__ __forceinline__ void exact_lex(const SceneDev& S, int k, F3 o, F3 d, F3 nd, LexAcc& h)
-{
-    float t;
-    const int kind = exact_hit(S, k, o, d, nd, t);
-    if (kind) lex_update(h, k, t, kind);
-}
-
-__device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev& L, const int n, const int q, float4* tile, const int* perm,
-                                              const int sub, const int nsub)
-{
-    const int lane = threadIdx.x & 63;
-    const bool live = q < n;
-    const int i = live ? (perm ? perm[q] : q) : 0;
-    F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
-    F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
-    F3 nd = normalized(d);
-    const bool abn = live && ray_abnormal(o, d, nd, S.guard);
-    const bool use = live && !abn;
-    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
-    F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
-    LexAcc h;
-    h.nearest = kMaxT; h.best = -1; h.overflow = false;
-#pragma unroll
-    for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
-    int* cand = reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + lane;  // cand[slot * 64]
-    unsigned short* queue = reinterpret_cast<unsigned short*>(reinterpret_cast<int*>(tile) + (threadIdx.x >> 6) * (kLaneLds / 4) + kCandCap * 64) + lane;  // queue[slot * 64]
-    int ncand = 0, flushes = 0, tested = 0;
-    auto flush = [&]() {
-        const int maxn = (int)wave_max((float)ncand);
-        for (int a = 0; a < maxn; a++)
-            if (a < ncand) exact_lex(S, cand[a * 64], o, d, nd, h);
-        tested += ncand; flushes++;
-        ncand = 0;
-    };
-    const int ncl = S.cseg[S.cnseg];
-    for (int phase = 0; phase < 2; phase++) {
-        const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
-        for (int cb = cbeg; cb < cend; cb += kQBatch) {
-            // (1) this round's cluster spheres: one coalesced load, then lane u's record is broadcast
-            unsigned cmask = 0u;
-            const int ce = min(kQBatch, cend - cb);
-            const int myc = S.corder[min(cb + (lane & (kQBatch - 1)), cend - 1)];
-            const float4 mine = S.cclR[myc];
-            for (int u = 0; u < ce; u++) {
-                float4 b;
-                b.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), u));
-                b.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), u));
-                b.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), u));
-                b.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.w), u));
-                if (!(cone_slack(o, nd, b) < 0.0f)) cmask |= 1u << u;
-            }
-            if (abn) cmask = (ce == 32) ? ~0u : ((1u << ce) - 1u);
-            if (!live) cmask = 0u;
-            if (phase == 1 && nsub == 4) cmask &= 0x11111111u << sub;  // split generation: this lane's quarter of the clusters
-            // (2) sub-cluster spheres of the lane's own passing clusters -> queue of (cluster slot, group mask)
-            int nq = 0;
-            while (__any(cmask != 0u)) {
-                const bool has = cmask != 0u;
-                const int u = has ? (__ffs(cmask) - 1) : 0;
-                cmask &= cmask - 1u;  // 0 stays 0
-                const int cid = __shfl(myc, u);
-                const float4* srec = S.csubR + (size_t)cid * 8;
-                unsigned gmask = 0u;
-#pragma unroll
-                for (int v = 0; v < 8; v++)
-                    if (!(cone_slack(o, nd, srec[v]) < 0.0f)) gmask |= 1u << v;
-                if (abn) gmask = 0xFFu;
-                if (has && gmask) { queue[nq * 64] = (unsigned short)((u << 8) | gmask); nq++; }
-            }
-            // (3) the members of the lane's own passing groups, one group of 8 per step
-            int qi = 0, cid = 0;
-            unsigned gm = 0u;
-            while (true) {
-                const bool refill = gm == 0u && qi < nq;
-                const unsigned e = refill ? (unsigned)queue[qi * 64] : 0u;
-                const int cnext = __shfl(myc, (int)(e >> 8));  // every lane takes part: ds_bpermute reads 0 from inactive lanes
-                if (refill) { qi++; gm = e & 0xFFu; cid = cnext; }
-                if (!__any(gm != 0u)) break;
-                const bool hasg = gm != 0u;
-                const int g = hasg ? (__ffs(gm) - 1) : 0;
-                gm &= gm - 1u;
-                const float4* mrec = S.cmem + (size_t)cid * 64 + g * 8;
-                const int* midx = S.cidx + (size_t)cid * 64 + g * 8;
-                float4 mb[kGroup];
-#pragma unroll
-                for (int v = 0; v < kGroup; v++) mb[v] = mrec[v];
-                unsigned acc = 0xFFFFFFFFu;
-#pragma unroll
-                for (int v = 0; v < kGroup; v++) acc &= __float_as_uint(filt(fo, fd, mb[v]));
-                if (hasg && (abn || (int)acc >= 0)) {
-#pragma unroll
-                    for (int v = 0; v < kGroup; v++) {
-                        if (abn || !(filt(fo, fd, mb[v]) < 0.0f)) {
-                            const int k = midx[v];
-                            if (k >= 0) { cand[ncand * 64] = k; ncand++; }
-                        }
-                    }
-                }
-                if (__any(ncand > kCandCap - kGroup)) flush();
-            }
-        }
-        flush();  // phase 0: every affine-sphere hit is known before the first plain sphere is tested
-    }
-    if (nsub == 4) {
-        // the four lanes of a ray hold the same affine list (phase 0 is not split) with their own kills, and
-        // their own nearest hit: an entry lives if no lane removed it, the lexicographic minimum wins
-#pragma unroll
-        for (int m = 1; m <= 2; m <<= 1) {
-            const float t2 = __shfl_xor(h.nearest, m);
-            const int b2 = __shfl_xor(h.best, m);
-            if (t2 < h.nearest || (t2 == h.nearest && b2 < h.best)) { h.nearest = t2; h.best = b2; }
-#pragma unroll
-            for (int e = 0; e < kAffList; e++) h.ak[e] = min(h.ak[e], __shfl_xor(h.ak[e], m));
-            h.overflow = h.overflow || (__shfl_xor((int)h.overflow, m) != 0);
-        }
-    }
-    bool alive = false;
-#pragma unroll
-    for (int e = 0; e < kAffList; e++) alive = alive || h.ak[e] >= 0;
-    float nearest = h.nearest;
-    int best = h.best;
-    int tflag = (best >= 0 && best < S.ns && alive) ? kTFlag : 0;
-    const bool slow = live && h.overflow;
-    if (__any(slow)) {
-        HitAcc hs;
-        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
-        const int nprim = S.ns + S.nt + S.np;
-        for (int k = 0; k < nprim; k++) {
-            const float4 b = S.bounds[k];
-            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
-        }
-        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
-    }
-    if (S.pstat) {
-        const unsigned long long sl = __ballot(slow);
-        const unsigned long long ab = __ballot(abn);
-        const float tot = wave_sum(live ? (float)tested : 0.0f);
-        if (lane == 0) {
-            atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, (unsigned long long)__popcll(sl) + ((unsigned long long)__popcll(ab) << 32));
-            atomicAdd(S.pstat + 2, (unsigned long long)flushes); atomicAdd(S.pstat + 3, (unsigned long long)tot);
-        }
-    }
-    if (live && sub == 0) {
-        L.t[i] = nearest;
-        L.prim[i] = (best < 0) ? -1 : (best | tflag);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Pooled traversal (the per-ray traversal above with the WORK, not the rays, spread over the lanes).
+// Pooled traversal: the WORK, not the rays, is spread over the lanes.
 //
-// In closest_lanes a lane walks its own ray's clusters, groups and candidates, and every loop runs as long
-// as the wave's busiest lane needs: measured on the benchmark frame, 147 member steps per wave where the
-// average lane needs 40, each step a round trip of per-lane gathers.  Here a wave owns R rays (64, or 16 for
+// Giving each lane its own ray to walk (the first version of this kernel) makes every loop run as long as the
+// wave's busiest lane needs: measured on the benchmark frame, 147 member steps per wave where the average lane
+// needs 55, each step a round trip of per-lane gathers.  Here a wave owns R rays (64, or 16 for
 // generations too small to fill the chip) whose data sit in LDS, and every stage is a list of independent
 // (ray, item) pairs in LDS that the 64 lanes consume 64 at a time, whoever the rays belong to:
 //   A  (ray, cluster sphere)          cone test                 64/R lanes per ray, kPoolQ clusters a round
@@ -657,8 +497,8 @@ __device__ __forceinline__ void closest_lanes(const SceneDev& S, const LevelDev&
 //   D  (ray, primitive)               the exact test             1 lane per pair    -> hits
 //   E  hits are handed to the lane that owns the ray (one per ray per step) and folded into its LexAcc.
 // Loads are coalesced (8 lanes read 128 consecutive bytes), a list's addresses are known ahead so several
-// steps' loads are in flight together, and no lane idles while another works.  What is tested is what
-// closest_lanes tests -- the same cone tests on the same spheres, the same filter, every surviving
+// steps' loads are in flight together, and no lane idles while another works.  What is tested is what a
+// per-lane walk tests -- the same cone tests on the same spheres, the same filter, every surviving
 // (ray, primitive) pair through the same exact test -- and LexAcc does not depend on the order of arrival,
 // except that affine-sphere clusters come first (phase 0 is drained before phase 1 starts).
 // ------------------------------------------------------------------------------------------------
@@ -693,7 +533,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 }
 
 template <int R>
-__device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W, const int* perm)
+__device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W)
 {
     constexpr int kPer = 64 / R;                                  // lanes per ray in stage A
     constexpr int kPoolQ = (kPoolB / R < 32) ? kPoolB / R : 32;   // clusters per round
@@ -702,7 +542,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     // ---- the wave's rays: lanes < R own one each ----
     const int q = q0 + lane;
     const bool live = lane < R && q < n;
-    const int i = live ? (perm ? perm[q] : q) : 0;
+    const int i = live ? q : 0;
     F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
     F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
     F3 nd = normalized(d);
@@ -964,7 +804,7 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
 }
 
 template <bool PREFETCH>
-__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays, const int* perm)
+__global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
 {
     __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps (2 KiB) and candidate lists (2 KiB)
     static_assert((kSegPrims / 32 + 512) * 4 * (kBlock / 64) <= kTile * 16, "bitmaps and lists fit");
@@ -972,46 +812,31 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
     if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;  // block-uniform
-        closest_packet<PREFETCH>(S, L, n, base, tile, perm);
+        closest_packet<PREFETCH>(S, L, n, base, tile);
     } else {
         if (blockIdx.x * 64 >= n) return;
         closest_thin(S, L, n, tile);
     }
 }
 
-// Generations of at most kSplitClosest rays put FOUR lanes on every ray (64 rays per workgroup): the lanes
-// share the affine-sphere clusters and take a quarter of the others each, and merge at the end.  A thin
-// generation has fewer waves than the chip has SIMDs; its run time is one wave's serial walk, now a
-// third as long.
+// Generations of at most kSplitClosest rays give a wave 16 rays instead of 64 (64 rays per workgroup): a thin
+// generation has fewer waves than the chip has SIMDs, its run time is one wave's serial walk, and the pooled
+// stages keep all 64 lanes busy whatever the number of rays.
 constexpr int kSplitClosest = 1 << 17;
 constexpr size_t kPrefetchRays = (size_t)1 << 22;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
-__global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, const int* perm)
+__global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
 {
-#ifdef RTX_LANES_OLD
-    __shared__ float4 tile[kLaneLds * (kBlock / 64) / 16];  // the four waves' candidate lists and cluster queues (40 KiB)
-    const int n = *nrays;
-    const int* pm = (perm && n > kThinRays) ? perm : nullptr;  // perm == nullptr: the host skipped the binning
-    if (n <= kSplitClosest) {
-        if (blockIdx.x * 64 >= n) return;  // block-uniform
-        closest_lanes(S, L, n, blockIdx.x * 64 + (threadIdx.x >> 2), tile, pm, threadIdx.x & 3, 4);
-    } else {
-        if (blockIdx.x * kBlock >= n) return;
-        closest_lanes(S, L, n, blockIdx.x * kBlock + threadIdx.x, tile, pm, 0, 1);
-    }
-#else
     __shared__ PoolLds pool[kBlock / 64];
     const int n = *nrays;
-    const int* pm = (perm && n > kThinRays) ? perm : nullptr;  // perm == nullptr: the host skipped the binning
     const int w = threadIdx.x >> 6;
     if (n <= kSplitClosest) {
         if (blockIdx.x * 64 >= n) return;  // block-uniform
-        closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w], pm);
+        closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w]);
     } else {
         if (blockIdx.x * kBlock >= n) return;
-        closest_pool<64>(S, L, n, blockIdx.x * kBlock + w * 64, pool[w], pm);
+        closest_pool<64>(S, L, n, blockIdx.x * kBlock + w * 64, pool[w]);
     }
-#endif
 }
 
 

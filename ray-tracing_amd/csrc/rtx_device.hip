@@ -85,12 +85,6 @@ struct rtx_context {
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
     unsigned long long* d_pstat = nullptr;
-    // The previous frame's generation sizes, written by its last kernel into pinned host memory: [chunk][level],
-    // -1 = not known.  ONLY a hint for the launch plan (a generation expected to be thin skips the ray binning
-    // launches): every kernel reads the true count on the device, a stale or torn hint costs time, never pixels.
-    int* h_hint = nullptr;
-    int hint_chunks = 0;
-    int* d_perm = nullptr; int* d_dummy = nullptr;
     // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
     // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream k % kSide with
     // that stream's own queue and scan buffers (fork after every set-up, one join per side stream before
@@ -105,7 +99,6 @@ struct rtx_context {
         bool used = false;
     } side[kSide];
     std::vector<hipEvent_t> ev_fork;
-    int* r_hist = nullptr; int* r_offs = nullptr; int* r_rank = nullptr; int* r_bsum = nullptr; int* r_braw = nullptr;
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
     int nframe_chunks = 0;
@@ -396,19 +389,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->dalloc(&sl.bsum, (maxbins + 1023) / 1024))) return rc;
             if ((rc = c->dalloc(&sl.braw, (maxbins + 1023) / 1024))) return rc;
         }
-        if ((rc = c->dalloc(&c->r_hist, (size_t)kRayBins))) return rc;
-        if ((rc = c->dalloc(&c->r_offs, (size_t)kRayBins))) return rc;
-        if ((rc = c->dalloc(&c->r_rank, (size_t)c->L[levels - 1].cap))) return rc;
-        if ((rc = c->dalloc(&c->r_bsum, (size_t)kRayBins / 1024))) return rc;
-        if ((rc = c->dalloc(&c->r_braw, (size_t)kRayBins / 1024))) return rc;
-        if ((rc = c->dalloc(&c->d_perm, (size_t)c->L[levels - 1].cap))) return rc;
-        if ((rc = c->dalloc(&c->d_dummy, (size_t)1))) return rc;
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels))) return rc;
     }
-    c->hint_chunks = std::max(c->nframe_chunks, 1);
-    HIPCHK(hipHostMalloc((void**)&c->h_hint, sizeof(int) * (size_t)c->hint_chunks * levels, hipHostMallocDefault));
-    for (int j = 0; j < c->hint_chunks * levels; j++) c->h_hint[j] = -1;
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     for (int i = 0; i < std::min(levels, (int)rtx_context::kSide); i++) {
@@ -462,29 +445,14 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             bound[k] = live_cap;
             int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             unsigned g = grid_for(live_cap);
-            const int* perm = nullptr;
-            // the last frame's size of this generation (pinned memory, written by that frame's k_accumulate)
-            const int hint = (nchunks < c->hint_chunks) ? *(volatile const int*)(c->h_hint + (size_t)nchunks * levels + k) : -1;
-            const bool expect_thin = hint >= 0 && hint <= kThinRays - kThinRays / 8;  // k_closest_lanes does not use the binned order then
-            if (k > 0 && !count && !exact_only && !expect_thin) {
-                // bin the secondary rays by (origin cell, direction cell) so that waves are coherent packets
-                HIPCHK(hipMemsetAsync(c->r_hist, 0, sizeof(int) * (size_t)kRayBins, st));
-                hipLaunchKernelGGL(k_ray_bin, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->r_hist, c->r_rank);
-                const int nb = kRayBins / 1024;
-                hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, c->r_hist, c->r_offs, kRayBins, c->r_bsum, c->r_braw, 1);
-                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, c->r_bsum, nb, c->d_dummy);
-                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, c->r_offs, kRayBins, c->r_bsum, c->r_braw, 1, (int*)nullptr);
-                hipLaunchKernelGGL(k_ray_scatter, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->r_offs, c->r_rank, c->d_perm);
-                perm = c->d_perm;
-            }
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) {
-                hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+                hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             }
-            else if (live_cap < kPrefetchRays) hipLaunchKernelGGL(k_closest_f<true>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
-            else hipLaunchKernelGGL(k_closest_f<false>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k, perm);
+            else if (live_cap < kPrefetchRays) hipLaunchKernelGGL(k_closest_f<true>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else hipLaunchKernelGGL(k_closest_f<false>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
             // generation 0 runs alone and every workgroup allocates: 1024-thread workgroups quarter its same-address
             // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits
@@ -535,8 +503,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
             hipLaunchKernelGGL(k_unwind, dim3(grid_for(bound[k])), dim3(kBlock), 0, st, c->S, Lk, Ln, nodes + k);
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels,
-                           c->h_hint + (size_t)std::min(nchunks, c->hint_chunks - 1) * levels);
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
     }
     if (nown > 0 && !(c->params.flags & RTX_F_NO_HALO))
         hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
@@ -581,7 +548,6 @@ void rtx_context_destroy(rtx_context* c)
         (void)hipSetDevice(c->device);
         if (c->rendered) (void)hipStreamSynchronize(c->last_stream);
         for (void* p : c->allocs) (void)hipFree(p);
-        if (c->h_hint) (void)hipHostFree(c->h_hint);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (auto e : c->kev) if (e) (void)hipEventDestroy(e);

@@ -275,12 +275,10 @@ __global__ __launch_bounds__(kBlock) void k_aa_quantise(const float* fimg, const
 }
 
 // counters of one chunk -> 64-bit frame totals
-// hint: pinned host memory; the next frame's launch plan reads the generation sizes from it (rtx_device.hip)
-__global__ void k_accumulate(const int* cnt, unsigned long long* totals, int levels, int* hint)
+__global__ void k_accumulate(const int* cnt, unsigned long long* totals, int levels)
 {
     int k = threadIdx.x;
     if (k < 2 * levels) totals[k] += (unsigned long long)cnt[k];
-    if (k < levels) hint[k] = cnt[k];
 }
 
 

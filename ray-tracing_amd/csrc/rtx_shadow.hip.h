@@ -59,64 +59,6 @@ __device__ __forceinline__ int light_cell(F3 v, int G)
 }
 
 
-// Secondary rays (reflection / refraction) of neighbouring pixels leave from different surfaces in
-// different directions.  Before a generation k >= 1 is traced its rays are counting-sorted by
-// (origin cell of a 16^3 grid over the scene box, 16 x 16 octahedral direction cell), Morton order,
-// and traced in that order through a permutation, so that a wave is again a packet with a small
-// origin sphere and a narrow cone.  Generations too thin for packet mode skip the sort.
-constexpr int kRayBins = 1 << 20;
-
-__device__ __forceinline__ unsigned morton3_4(unsigned x)  // 4 bits -> every third bit
-{
-    x &= 0xfu;
-    x = (x | (x << 4)) & 0x0c3u;
-    x = (x | (x << 2)) & 0x249u;
-    return x;
-}
-
-__device__ __forceinline__ int ray_key(const SceneDev& S, F3 o, F3 d)
-{
-    int cx = (int)fminf(fmaxf((o.x - S.box_lo.x) * S.box_inv.x, 0.0f), 15.0f);
-    int cy = (int)fminf(fmaxf((o.y - S.box_lo.y) * S.box_inv.y, 0.0f), 15.0f);
-    int cz = (int)fminf(fmaxf((o.z - S.box_lo.z) * S.box_inv.z, 0.0f), 15.0f);
-    unsigned oc = morton3_4((unsigned)cx) | (morton3_4((unsigned)cy) << 1) | (morton3_4((unsigned)cz) << 2);
-    return (int)((oc << 8) | (unsigned)light_cell(d, 16));
-}
-
-__global__ __launch_bounds__(kBlock) void k_ray_bin(SceneDev S, LevelDev L, const int* nrays, int* hist, int* rank)
-{
-    const int n = *nrays;
-    if (n <= kThinRays) return;  // thin generations are not traced in packet mode
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n;
-    int key = -1;
-    if (live) key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
-    int myrank = 0;
-    unsigned long long pending = __ballot(live);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int k0 = __shfl(key, leader);
-        const unsigned long long same = __ballot(live && key == k0) & pending;
-        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-        int base = 0;
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
-        base = __shfl(base, leader);
-        if ((same >> (threadIdx.x & 63)) & 1ull) myrank = base + prefix;
-        pending &= ~same;
-    }
-    if (live) rank[i] = myrank;
-}
-
-__global__ __launch_bounds__(kBlock) void k_ray_scatter(SceneDev S, LevelDev L, const int* nrays, const int* offs, const int* rank, int* perm)
-{
-    const int n = *nrays;
-    if (n <= kThinRays) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int key = ray_key(S, f3(L.ox[i], L.oy[i], L.oz[i]), f3(L.dx[i], L.dy[i], L.dz[i]));
-    perm[offs[key] + rank[i]] = i;
-}
-
 struct ShadowRay { F3 o, ld; int key; };
 
 __device__ __forceinline__ ShadowRay make_shadow_ray(const SceneDev& S, const LevelDev& L, int j, int li, int G)
