@@ -379,10 +379,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         const int nside = std::min(levels, (int)rtx_context::kSide);
         for (int i = 0; i < nside; i++) {
             rtx_context::ShadowLane& sl = c->side[i];
-            float** fl[] = {&sl.q.ox, &sl.q.oy, &sl.q.oz, &sl.q.dx, &sl.q.dy, &sl.q.dz};
-            for (float** f : fl)
-                if ((rc = c->dalloc(f, qcap))) return rc;
-            if ((rc = c->dalloc(&sl.q.id, qcap))) return rc;
+            if ((rc = c->dalloc(&sl.q.a, qcap))) return rc;
+            if ((rc = c->dalloc(&sl.q.b, qcap))) return rc;
             if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
             if ((rc = c->dalloc(&sl.offs, maxbins))) return rc;
             if ((rc = c->dalloc(&sl.rank, qcap))) return rc;
@@ -480,7 +478,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                     const int nb = (c->nbins + 1023) / 1024;
                     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.id);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
                 }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups

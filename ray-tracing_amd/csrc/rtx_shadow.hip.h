@@ -25,7 +25,10 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
 // materialised once per generation into a queue sorted by (light, direction cell) (k_shadow_bin, k_scan_*,
 // k_shadow_scatter) and traced by k_shadow_pass as packets with their apex at the light: plain spheres
 // and triangles through the shadow cluster hierarchy, affine spheres through a strip test of their own.
-struct ShadowQ { float *ox, *oy, *oz, *dx, *dy, *dz; int* id; };
+// One 32-byte record per queued ray, a = { o.xyz, ld.x }, b = { ld.y, ld.z, id (bits), - }: the scatter writes a ray to a
+// slot of its own, two 16-byte stores into one 32-byte sector where seven 4-byte arrays took seven sectors (the
+// scatter is bound by the number of memory requests, not by bytes); the pass reads two wide coalesced loads.
+struct ShadowQ { float4 *a, *b; };
 
 // Light-space binning.  Every shadow ray's line passes through its light, so rays towards one light
 // that leave it in nearly the same direction are nearly the same line, wherever their hit points
@@ -148,15 +151,15 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int*
     if (t == 1023) *qcount = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, int* pad_ids)
+__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, float4* pad_b)
 {
     const int b = blockIdx.x * 1024 + threadIdx.x;
     const int start = bsum[blockIdx.x];
     if (b < nbins) offs[b] += start;
-    if (pad_ids) {
+    if (pad_b) {
         const int raw = braw[blockIdx.x];
         const int pad = (raw + align - 1) / align * align - raw;
-        if ((int)threadIdx.x < pad) pad_ids[start + raw + threadIdx.x] = -1;
+        if ((int)threadIdx.x < pad) pad_b[start + raw + threadIdx.x] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
     }
 }
 
@@ -169,9 +172,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
     if (j >= n) return;
     ShadowRay r = make_shadow_ray(S, L, j, li, G);
     const int q = offs[r.key] + rank[li * n + j];
-    Q.ox[q] = r.o.x; Q.oy[q] = r.o.y; Q.oz[q] = r.o.z;
-    Q.dx[q] = r.ld.x; Q.dy[q] = r.ld.y; Q.dz[q] = r.ld.z;
-    Q.id[q] = li * L.cap + j;
+    Q.a[q] = make_float4(r.o.x, r.o.y, r.o.z, r.ld.x);
+    Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), 0.0f);
 }
 
 // Affine spheres.  The reference maps only the
@@ -299,10 +301,11 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     const int lane = threadIdx.x & 63;
     const int i = base + threadIdx.x;
     const int ii = (i < n) ? i : 0;
-    const int id = Qi.id[ii];
+    const float4 qa = Qi.a[ii], qb = Qi.b[ii];
+    const int id = __float_as_int(qb.z);
     const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
-    F3 o = f3(Qi.ox[ii], Qi.oy[ii], Qi.oz[ii]);
-    F3 ld = f3(Qi.dx[ii], Qi.dy[ii], Qi.dz[ii]);
+    F3 o = f3(qa.x, qa.y, qa.z);
+    F3 ld = f3(qa.w, qb.x, qb.y);
     F3 nld = normalized(ld);
     const bool abn = ray_abnormal(o, ld, nld, S.guard);
     const bool use = live && !abn;
