@@ -32,6 +32,29 @@ __device__ __forceinline__ float filt(F3 fo, F3 fd, float4 b)
     return __builtin_fmaf(bh, bh, -cc);
 }
 
+// The filter with the half-space behind the ray's origin taken out (plain spheres, triangles and polygons only:
+// NOT affine spheres, whose object-space ray the reference builds with the translation added to the direction).
+// The reference's tests accept a hit only at t >= 0 (sphere: both roots negative is a miss, :217-222; triangle:
+// t < 0 is a miss, :347) and the hit point p = o + t n lies in the primitive's bounding sphere (c, R)
+// (rtx_bounds.cpp), so n.(p - o) = t >= 0; a sphere entirely behind the origin, n.(o - c) > R, has
+// n.(p - o) <= n.(c - o) + R < 0 for each of its points: no hit.  Taken with a margin: bh^2 > 1.01 R^2 + 1e-6 |X|^2
+// puts n.(o - c) at least 5e-5 |o - c| beyond R for every ratio |o - c| / R, fifty times the rounding of the
+// reference's b, c and t at that distance.  NaN operands and R = inf (records that always pass) compare false:
+// no cull.  A zero direction (point query) has bh = 0: no cull.
+__device__ __forceinline__ bool filt_front(F3 fo, F3 fd, float4 b)  // true: the exact test may accept
+{
+    float X = fo.x - b.x, Y = fo.y - b.y, Z = fo.z - b.z;
+    float bh = fd.z * Z;
+    bh = __builtin_fmaf(fd.y, Y, bh);
+    bh = __builtin_fmaf(fd.x, X, bh);
+    float cc = __builtin_fmaf(Z, Z, b.w);
+    cc = __builtin_fmaf(Y, Y, cc);
+    cc = __builtin_fmaf(X, X, cc);
+    const float F = __builtin_fmaf(bh, bh, -cc);
+    const bool behind = bh > 0.0f && bh * bh > __builtin_fmaf(-1.01f, b.w, 1e-6f * (cc - b.w));
+    return !(F < 0.0f) && !behind;
+}
+
 __device__ __forceinline__ bool finite3(F3 v)
 {
     return (fabsf(v.x) <= 3.0e38f) && (fabsf(v.y) <= 3.0e38f) && (fabsf(v.z) <= 3.0e38f);
@@ -248,6 +271,22 @@ __device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
     float h2 = (C2 - a * a) - 4e-6f * C2;
     float rhs = (b.w * 1.00001f + 1e-20f) + a * sinE;
     return rhs * rhs * 1.00001f - h2 * cosE2;
+}
+
+// cone_slack with the half-space behind the origin taken out (see filt_front; b = { c, R } encloses bounding
+// spheres of plain primitives only): sign bit set = no member can be hit.
+__device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
+{
+    const float cosE2 = 0.9999783f;
+    const float sinE = 3.705e-3f;
+    float Cx = b.x - o.x, Cy = b.y - o.y, Cz = b.z - o.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float as = n.x * Cx + n.y * Cy + n.z * Cz;
+    float a = fabsf(as);
+    float h2 = (C2 - a * a) - 4e-6f * C2;
+    float rhs = (b.w * 1.00001f + 1e-20f) + a * sinE;
+    const bool behind = as < 0.0f && as * as > 1.01f * b.w * b.w + 1e-6f * C2;
+    return behind ? -1.0f : rhs * rhs * 1.00001f - h2 * cosE2;
 }
 
 template <bool PREFETCH>
@@ -562,6 +601,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
 #pragma unroll
     for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
     int nC = 0, nD = 0, tested = 0;
+    bool front = false;  // phase 1 (no affine spheres): primitives behind the ray's origin are skipped
 
     // E: hand the hits of a D step to the owners of their rays, one hit per ray per round
     auto deliver = [&](bool pending, int rr, int k, float t, int kind) {
@@ -614,7 +654,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         unsigned pmask = 0u;
 #pragma unroll
         for (int v = 0; v < kGroup; v++)
-            if (kk[v] >= 0 && (!use || !(filt(fo, fd, mb[v]) < 0.0f))) pmask |= 1u << v;
+            if (kk[v] >= 0 && (!use || (front ? filt_front(fo, fd, mb[v]) : !(filt(fo, fd, mb[v]) < 0.0f)))) pmask |= 1u << v;
         if (!has) pmask = 0u;
         // pushes in MEMBER order: neighbouring lanes (rays of one group) that pass the same member sit together in D
 #pragma unroll
@@ -644,7 +684,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         unsigned gmask = 0u;
 #pragma unroll
         for (int v = 0; v < 8; v++)
-            if (rabn || !(cone_slack(ro, rn, sb[v]) < 0.0f)) gmask |= 1u << v;
+            if (rabn || !((front ? cone_slack_front(ro, rn, sb[v]) : cone_slack(ro, rn, sb[v])) < 0.0f)) gmask |= 1u << v;
         if (!has) gmask = 0u;
         // pushes in GROUP order (the lanes are already in cluster order): the 64 entries of a C step then name
         // few distinct groups, whose members neighbouring lanes read together; a C step as soon as 64 entries wait
@@ -662,6 +702,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     const int ncl = S.cseg[S.cnseg];
     for (int phase = 0; phase < 2; phase++) {
         const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
+        front = phase == 1;
         for (int cb = cbeg; cb < cend; cb += kPoolQ) {
             const int ce = min(kPoolQ, cend - cb);
             // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
@@ -674,7 +715,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
             unsigned cmask = 0u;
             for (int u = part; u < ce; u += kPer) {
                 const float4 b = W.csph[u];
-                if (aabn || !(cone_slack(ao, an, b) < 0.0f)) cmask |= 1u << u;
+                if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << u;
             }
             if (!alive) cmask = 0u;
             // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same

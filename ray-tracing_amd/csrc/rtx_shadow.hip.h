@@ -411,7 +411,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         const int u = __ffsll((long long)mm) - 1;
                         mm &= mm - 1;
                         const float4 br = bcast4(mb, u);
-                        if (!done && !(filt(fo, fd, br) < 0.0f)) {
+                        if (!done && filt_front(fo, fd, br)) {
                             if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
                                 done = true;
                                 fo = f3(1e18f, 0.0f, 0.0f);
