@@ -114,6 +114,36 @@ def test_culling_is_exact_with_general_affine_matrices(rt, gpu, tmp_path, size):
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
 
 
+def test_culling_is_exact_beyond_the_affine_table(rt, gpu, tmp_path):
+    """Shadow passes without the (light, direction cell) table of affine spheres: 5,000 affine spheres are more
+    than the table holds (4,096), so every wave strip-tests all of them; and a light INSIDE a scene whose hit
+    points lie further from it than the far corner of the box of the bounded primitives cannot happen by
+    construction, so the table's range check is exercised the other way: a second, tiny scene whose only
+    bounded primitives are small and near the light while the rays hit a huge polygon (polygons have no bounding
+    sphere and are not part of the box) far outside it."""
+    p = tmp_path / "many_affine.txt"
+    rt.scenegen.write_scene(str(p), 5000, 200, rt.scenegen.lights_c4(), seed=11, frac_affine=1.0, frac_reflective=0.3)
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(240, 135, 2))
+    b, sb = rt.render_f32(sc, rt.Params.make(240, 135, 2, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    q = tmp_path / "far_hits.txt"
+    q.write_text("6\ncamera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0.05 0.05 0.05\n"
+                 "light 0 30 -20 0.6 0.6 0.6\n"
+                 "sphere 0 0 -20 1  1 0 0  1 0 1  .4 .4 .4  .5 0 1 0 3\n"
+                 "sphere 3 1 -22 1.5  0 1 0  .2 .9 .2  .5 .5 .5  0 0 1 1 12  2 0 0  0 1 0  0 0 .5  0 0 0\n"
+                 "polygon 4 -900 -12 100  900 -12 100  900 -12 -3000  -900 -12 -3000   0.8 0.8 0.9  .5 .5 .55  .3 .3 .3  0.4 0 1 12\n"
+                 "triangle -2 4 -18  2 4 -18  0 4 -24  .8 .6 .7  .5 .4 .5  .1 .1 .1  0 0 1 4\n")
+    sc2 = rt.load_scene(str(q))
+    a, sa = rt.render_f32(sc2, rt.Params.make(320, 180, 3))
+    b, sb = rt.render_f32(sc2, rt.Params.make(320, 180, 3, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
 def test_general_affine_scene_matches_oracle(rt, oracle, gpu, tmp_path):
     """A generated scene the reference's authors never saw: 300 spheres (half affine, general matrices,
     translation rows, singular ones) + 300 triangles, reflective and refractive, against the CPU oracle."""
