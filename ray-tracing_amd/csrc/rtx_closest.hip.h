@@ -212,15 +212,16 @@ __device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, 
     const F3 sd = f3(__shfl(nd.x, src), __shfl(nd.y, src), __shfl(nd.z, src));
     F3 oo = f3(live ? o.x : so.x, live ? o.y : so.y, live ? o.z : so.z);
     F3 dd = f3(live ? nd.x : sd.x, live ? nd.y : sd.y, live ? nd.z : sd.z);
-    float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
-    P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
-    float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
-    P.rho = wave_max(fsqrt(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
-    if (apex_ok) {  // wave-uniform
+    if (apex_ok) {  // wave-uniform: one reduction instead of the seven of the origins' bounding sphere
         float ax = oo.x - apex.x, ay = oo.y - apex.y, az = oo.z - apex.z;
         float maxD = wave_max(fsqrt(ax * ax + ay * ay + az * az));
-        float rho_apex = 1.3e-4f + 3.8e-3f * maxD;
-        if (rho_apex < P.rho) { P.rho = rho_apex; P.co = apex; }
+        P.rho = 1.3e-4f + 3.8e-3f * maxD;
+        P.co = apex;
+    } else {
+        float lx = wave_min(oo.x), hx = wave_max(oo.x), ly = wave_min(oo.y), hy = wave_max(oo.y), lz = wave_min(oo.z), hz = wave_max(oo.z);
+        P.co = f3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+        float ex = oo.x - P.co.x, ey = oo.y - P.co.y, ez = oo.z - P.co.z;
+        P.rho = wave_max(fsqrt(ex * ex + ey * ey + ez * ez)) * 1.00002f + 1e-30f;
     }
     F3 sw = f3(wave_sum(dd.x), wave_sum(dd.y), wave_sum(dd.z));
     float sn = fsqrt(sw.x * sw.x + sw.y * sw.y + sw.z * sw.z);

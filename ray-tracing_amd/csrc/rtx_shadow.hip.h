@@ -25,7 +25,7 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
 // materialised once per generation into a queue sorted by (light, direction cell) (k_shadow_bin, k_scan_*,
 // k_shadow_scatter) and traced by k_shadow_pass as packets with their apex at the light: plain spheres
 // and triangles through the shadow cluster hierarchy, affine spheres through a strip test of their own.
-// One 32-byte record per queued ray, a = { o.xyz, ld.x }, b = { ld.y, ld.z, id (bits), - }: the scatter writes a ray to a
+// One 32-byte record per queued ray, a = { o.xyz, ld.x }, b = { ld.y, ld.z, id (bits), affine-table key (bits) }: the scatter writes a ray to a
 // slot of its own, two 16-byte stores into one 32-byte sector where seven 4-byte arrays took seven sectors (the
 // scatter is bound by the number of memory requests, not by bytes); the pass reads two wide coalesced loads.
 struct ShadowQ { float4 *a, *b; };
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
     ShadowRay r = make_shadow_ray(S, L, j, li, G);
     const int q = offs[r.key] + rank[li * n + j];
     Q.a[q] = make_float4(r.o.x, r.o.y, r.o.z, r.ld.x);
-    Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), 0.0f);
+    // the ray's (light, cell) key of the affine table rides along in the record's spare word
+    const int akey = S.aff_dt ? li * S.aff_G * S.aff_G + light_cell(r.ld, S.aff_G) : 0;
+    Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), __int_as_float(akey));
 }
 
 // Affine spheres.  The reference maps only the
@@ -339,7 +341,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             const float lx = Lp.x - o.x, ly = Lp.y - o.y, lz = Lp.z - o.z;
             const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
             covered = dist <= S.aff_dt[li] && dist >= 1e-2f;
-            key = li * S.aff_G * S.aff_G + light_cell(ld, S.aff_G);
+            key = __float_as_int(qb.w);  // li * G * G + light_cell(ld, G), computed by k_shadow_scatter
         }
         if (__all(covered)) {
             unsigned long long acc = 0ull;
@@ -433,7 +435,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
             //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
             // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
-            if (!out && S.naff > 0) {
+            if (!out && S.naff > 0 && nlist > 0) {
                 const F3 Lr = one_light ? apex : P.co;
                 const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
                 const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
