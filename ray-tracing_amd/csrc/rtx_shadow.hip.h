@@ -174,7 +174,14 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
     const int q = offs[r.key] + rank[li * n + j];
     Q.a[q] = make_float4(r.o.x, r.o.y, r.o.z, r.ld.x);
     // the ray's (light, cell) key of the affine table rides along in the record's spare word
-    const int akey = S.aff_dt ? li * S.aff_G * S.aff_G + light_cell(r.ld, S.aff_G) : 0;
+    // (-2: the table does not cover this ray -- further from its light than the table's range, or on top of it)
+    int akey = 0;
+    if (S.aff_dt) {
+        const rtx_light& Lt = S.lights[li];
+        const float lx = Lt.point.x - r.o.x, ly = Lt.point.y - r.o.y, lz = Lt.point.z - r.o.z;
+        const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
+        akey = (dist <= S.aff_dt[li] && dist >= 1e-2f) ? li * S.aff_G * S.aff_G + light_cell(r.ld, S.aff_G) : -2;
+    }
     Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), __int_as_float(akey));
 }
 
@@ -337,11 +344,8 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         bool covered = true;
         int key = -1;
         if (live && !abn) {  // abnormal rays take the transposed scan over everything below
-            const F3 Lp = f3(S.lights[li].point);
-            const float lx = Lp.x - o.x, ly = Lp.y - o.y, lz = Lp.z - o.z;
-            const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
-            covered = dist <= S.aff_dt[li] && dist >= 1e-2f;
-            key = __float_as_int(qb.w);  // li * G * G + light_cell(ld, G), computed by k_shadow_scatter
+            key = __float_as_int(qb.w);  // li * G * G + light_cell(ld, G), or -2: not covered (k_shadow_scatter)
+            covered = key != -2;
         }
         if (__all(covered)) {
             unsigned long long acc = 0ull;

@@ -12,6 +12,6 @@ for md in (0, 1, 2, 3, 4):
     ps = list(st.packet_stats)
     d = [a - b for a, b in zip(ps, prev)]; prev = ps
     print("level %d rays %d: frame ms %.2f" % (md, st.rays_level[md], st.ms_total))
-    print("  closest: waves %d slow %d abn %d flushes/wave %.1f tested/ray %.1f" % (d[0], d[1] & 0xffffffff, d[1] >> 32, d[2]/max(d[0],1), d[3]/max(st.rays_level[md],1)))
+    print("  closest: waves %d slow %d abn %d tested/ray %.1f" % (d[0], d[1] & 0xffffffff, d[1] >> 32, d[3]/max(st.rays_level[md],1)))
     print("  shadow : blocks %d ok %d fallback rays %d batches/block %.1f survivors/block %.1f" % (d[4], d[5] & 0xffffffff, d[5] >> 32, d[6]/max(d[4],1), d[7]/max(d[4],1)))
     ctx.close()
