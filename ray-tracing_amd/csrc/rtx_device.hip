@@ -478,7 +478,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                     const int nb = (c->nbins + 1023) / 1024;
                     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
                 }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups

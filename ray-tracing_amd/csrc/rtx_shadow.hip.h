@@ -87,21 +87,28 @@ __global__ __launch_bounds__(kBlock) void k_shadow_bin(SceneDev S, LevelDev L, c
         key = make_shadow_ray(S, L, j, li, G).key;
         L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
     }
-    // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key
-    // per wave (leader election on the first pending lane's key) instead of one per ray.
-    int myrank = 0;
+    // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key per wave
+    // instead of one per ray.  The groups are formed first (ballots only: leader, size, place in the group),
+    // then every leader issues its atomic in ONE instruction and the wave waits for one round trip, where a
+    // loop of atomic-then-broadcast waited for one per distinct key.
+    const int lane = threadIdx.x & 63;
+    int leader_of = lane, prefix = 0, count = 0;
     unsigned long long pending = __ballot(live);
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int k0 = __shfl(key, leader);
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
         const unsigned long long same = __ballot(live && key == k0) & pending;
-        const int prefix = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-        int base = 0;
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(hist + k0, __popcll(same));
-        base = __shfl(base, leader);
-        if (live && key == k0 && ((same >> (threadIdx.x & 63)) & 1ull)) myrank = base + prefix;
+        if ((same >> lane) & 1ull) {
+            leader_of = leader;
+            prefix = __popcll(same & ((1ull << lane) - 1ull));
+            count = __popcll(same);
+        }
         pending &= ~same;
     }
+    int base = 0;
+    if (live && leader_of == lane) base = atomicAdd(hist + key, count);
+    base = __shfl(base, leader_of);
+    const int myrank = base + prefix;
     if (live) rank[li * n + j] = myrank;
 }
 
@@ -151,15 +158,19 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int* bsum, int nblocks, int*
     if (t == 1023) *qcount = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, float4* pad_b)
+// (256-thread workgroups: a 1024-thread one waits for a whole CU to drain when the chip is busy with the
+// closest-hit kernel of the next generation, and this kernel sits between the sort and the shadow pass)
+__global__ __launch_bounds__(kBlock) void k_scan_add(int* offs, int nbins, const int* bsum, const int* braw, int align, float4* pad_b)
 {
-    const int b = blockIdx.x * 1024 + threadIdx.x;
-    const int start = bsum[blockIdx.x];
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    const int blk = b >> 10, t = b & 1023;  // the 1024-bin group of k_scan_blocks this bin belongs to
+    if (blk >= (nbins + 1023) / 1024) return;
+    const int start = bsum[blk];
     if (b < nbins) offs[b] += start;
     if (pad_b) {
-        const int raw = braw[blockIdx.x];
+        const int raw = braw[blk];
         const int pad = (raw + align - 1) / align * align - raw;
-        if ((int)threadIdx.x < pad) pad_b[start + raw + threadIdx.x] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+        if (t < pad) pad_b[start + raw + t] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
     }
 }
 
