@@ -87,18 +87,15 @@ struct rtx_context {
     unsigned long long* d_pstat = nullptr;
     // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
     // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream k % kSide with
-    // that stream's own queue and scan buffers (fork after every set-up, one join per side stream before
-    // the unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
-    // The ray binning of the closest-hit pass has scan buffers of its own for the same reason.
+    // that stream's own queue and scan buffers (fork after every set-up, one join per generation before
+    // its own unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
     static constexpr int kSide = 3;
     struct ShadowLane {
         hipStream_t stream = nullptr;
-        hipEvent_t join = nullptr;
         ShadowQ q = {};
         int* hist = nullptr; int* offs = nullptr; int* rank = nullptr; int* bsum = nullptr; int* braw = nullptr;
-        bool used = false;
     } side[kSide];
-    std::vector<hipEvent_t> ev_fork;
+    std::vector<hipEvent_t> ev_fork, ev_pass;  // per generation: set-up done (main stream), shadow pass done (side stream)
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
     int nframe_chunks = 0;
@@ -394,10 +391,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     HIPCHK(hipEventCreate(&c->ev1));
     for (int i = 0; i < std::min(levels, (int)rtx_context::kSide); i++) {
         HIPCHK(hipStreamCreateWithFlags(&c->side[i].stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->side[i].join, hipEventDisableTiming));
     }
     c->ev_fork.resize(levels);
     for (auto& e : c->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_pass.resize(levels);
+    for (auto& e : c->ev_pass) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (params->flags & RTX_F_TIME_KERNELS) {
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->kev.resize((size_t)nchunks * levels * 2 * 2);  // (start, stop) x (closest, shadow) per generation and chunk
@@ -437,6 +435,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
         size_t live_cap = npix;  // upper bound on live rays at this level
         std::vector<size_t> bound(levels);
+        std::vector<char> forked(levels, 0);
         for (int k = 0; k < levels; k++) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
             LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
@@ -470,7 +469,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 hipStream_t ss = sl.stream;
                 HIPCHK(hipEventRecord(c->ev_fork[k], st));
                 HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
-                sl.used = true;
+                forked[k] = true;
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
                 HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
                 hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
@@ -487,18 +486,14 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
                 hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
+                HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }
             if (c->fanout >= 2) live_cap *= 2;
         }
-        for (rtx_context::ShadowLane& sl : c->side)
-            if (sl.used) {
-                HIPCHK(hipEventRecord(sl.join, sl.stream));
-                HIPCHK(hipStreamWaitEvent(st, sl.join, 0));
-                sl.used = false;
-            }
         for (int k = levels - 1; k >= 0; k--) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
             LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
+            if (forked[k]) HIPCHK(hipStreamWaitEvent(st, c->ev_pass[k], 0));  // generation k's lit flags
             hipLaunchKernelGGL(k_unwind, dim3(grid_for(bound[k])), dim3(kBlock), 0, st, c->S, Lk, Ln, nodes + k);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
@@ -550,8 +545,8 @@ void rtx_context_destroy(rtx_context* c)
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
         for (auto e : c->ev_fork) if (e) (void)hipEventDestroy(e);
+        for (auto e : c->ev_pass) if (e) (void)hipEventDestroy(e);
         for (rtx_context::ShadowLane& sl : c->side) {
-            if (sl.join) (void)hipEventDestroy(sl.join);
             if (sl.stream) (void)hipStreamDestroy(sl.stream);
         }
     }
