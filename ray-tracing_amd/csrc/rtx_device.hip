@@ -498,9 +498,15 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
         }
         hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, c->d_cnt, c->d_totals, levels);
     }
-    if (nown > 0 && !(c->params.flags & RTX_F_NO_HALO))
-        hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
-                           c->d_own_rows, nown, W, c->height, d_out ? d_out : c->d_rgb8);
+    if (nown > 0 && !(c->params.flags & RTX_F_NO_HALO)) {
+        unsigned char* dst = d_out ? d_out : c->d_rgb8;
+        if ((W & 3) == 0 && ((uintptr_t)dst & 3) == 0 && ((uintptr_t)c->d_fimg & 15) == 0)
+            hipLaunchKernelGGL(k_aa_quantise4, dim3(grid_for((size_t)nown * (W / 4))), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
+                               c->d_own_rows, nown, W, c->height, dst);
+        else
+            hipLaunchKernelGGL(k_aa_quantise, dim3(grid_for((size_t)nown * W)), dim3(kBlock), 0, st, c->d_fimg, c->d_row2ti,
+                               c->d_own_rows, nown, W, c->height, dst);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, st));
     c->last_stream = st;

@@ -274,6 +274,65 @@ __global__ __launch_bounds__(kBlock) void k_aa_quantise(const float* fimg, const
     out[3 * (size_t)i + 2] = quantise(az);
 }
 
+// The same for FOUR neighbouring pixels per thread (width a multiple of 4, output dword-aligned): the 3 x 6 window
+// comes in with three 16-byte loads per row instead of 27 dword loads per pixel, the 12 output bytes leave as three
+// dwords.  Every pixel's sum is formed in the reference's order (rows top to bottom, left to right, the centre
+// doubled), so the bytes are those of k_aa_quantise.
+__global__ __launch_bounds__(kBlock) void k_aa_quantise4(const float* fimg, const int* row2ti, const int* own_rows,
+                                                         int nown, int width, int height, unsigned char* out)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;       // group of 4 pixels
+    const int wq = width >> 2;
+    if (q >= nown * wq) return;
+    const int r = q / wq, x0 = (q - r * wq) << 2;
+    const int y = own_rows[r];
+    float win[3][6][3];
+    bool rowok[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        const int yv = y - 1 + dy;
+        rowok[dy] = yv >= 0 && yv < height;
+        const float* p = fimg + ((size_t)row2ti[rowok[dy] ? yv : y] * width + x0) * 3;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4), c = *reinterpret_cast<const float4*>(p + 8);
+        const float m[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) win[dy][k + 1][ch] = m[k * 3 + ch];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            win[dy][0][ch] = (x0 > 0) ? p[-3 + ch] : 0.0f;
+            win[dy][5][ch] = (x0 + 4 < width) ? p[12 + ch] : 0.0f;
+        }
+    }
+    unsigned char bytes[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x0 + k;
+        float counter = 0.0f, ax = 0.0f, ay = 0.0f, az = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int xv = x - 1 + dx;
+                if (rowok[dy] && xv >= 0 && xv < width) {
+                    const float* pv = win[dy][k + dx];
+                    counter = counter + 1.0f;
+                    if (dy == 1 && dx == 1) { ax += 2.0f * pv[0]; ay += 2.0f * pv[1]; az += 2.0f * pv[2]; }
+                    else { ax += pv[0]; ay += pv[1]; az += pv[2]; }
+                }
+            }
+        const float dv = counter + 1.0f;
+        bytes[3 * k + 0] = quantise(ax / dv);
+        bytes[3 * k + 1] = quantise(ay / dv);
+        bytes[3 * k + 2] = quantise(az / dv);
+    }
+    unsigned int* o = reinterpret_cast<unsigned int*>(out + 12 * (size_t)q);
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        o[j] = (unsigned)bytes[4 * j] | ((unsigned)bytes[4 * j + 1] << 8) | ((unsigned)bytes[4 * j + 2] << 16) | ((unsigned)bytes[4 * j + 3] << 24);
+}
+
 // counters of one chunk -> 64-bit frame totals
 __global__ void k_accumulate(const int* cnt, unsigned long long* totals, int levels)
 {
