@@ -144,6 +144,27 @@ def test_culling_is_exact_beyond_the_affine_table(rt, gpu, tmp_path):
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_culled_equals_exact(rt, gpu, tmp_path, seed):
+    """Random scenes (counts, lights -- also inside the scene --, affine share and kind, radii, edge lengths, depth
+    drawn per seed): every culling stage of the default kernels against the exact-only kernels, bit for bit."""
+    rng = np.random.default_rng(seed)
+    ns, nt, nl = int(rng.integers(50, 4000)), int(rng.integers(0, 4000)), int(rng.integers(1, 6))
+    lights = [(float(rng.uniform(-45, 45)), float(rng.uniform(-30, 45)), float(rng.uniform(-130, 20)), 0.3, 0.3, 0.3) for _ in range(nl)]
+    p = tmp_path / ("fuzz_%d.txt" % seed)
+    rt.scenegen.write_scene(str(p), ns, nt, lights, seed=1000 + seed, frac_affine=float(rng.uniform(0, 0.6)),
+                            frac_reflective=float(rng.uniform(0.1, 0.8)), frac_refractive=float(rng.uniform(0, 0.4)),
+                            affine="general" if seed % 2 else "diag", radius=(0.2, float(rng.uniform(0.5, 5.0))),
+                            edge=float(rng.uniform(0.5, 10.0)))
+    sc = rt.load_scene(str(p))
+    md = int(rng.integers(1, 6))
+    a, sa = rt.render_f32(sc, rt.Params.make(480, 270, md))
+    b, sb = rt.render_f32(sc, rt.Params.make(480, 270, md, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
 def test_general_affine_scene_matches_oracle(rt, oracle, gpu, tmp_path):
     """A generated scene the reference's authors never saw: 300 spheres (half affine, general matrices,
     translation rows, singular ones) + 300 triangles, reflective and refractive, against the CPU oracle."""
