@@ -17,9 +17,19 @@ class BandGather:
         self.rows = [host.band_rows(height, world, r, band_rows) for r in range(world)]
         self.slot = max(len(r) for r in self.rows) * width * 3   # equal-sized slots: pad to the largest band
         self.send = torch.zeros(self.slot, dtype=torch.uint8, device=device)
-        self.recv = [torch.empty(self.slot, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
         self.frame = torch.empty((height, width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
-        self.row_index = [torch.as_tensor(np.asarray(r, dtype=np.int64), device=device) for r in self.rows] if rank == 0 else None
+        if rank == 0:
+            # one contiguous receive buffer (the gather's per-rank tensors are views of it), and the two index
+            # vectors that move every received row to its place in ONE gather + scatter instead of one per rank
+            maxrows = self.slot // (width * 3)
+            self.recv_all = torch.empty((world * maxrows, width, 3), dtype=torch.uint8, device=device)
+            self.recv = [self.recv_all[r * maxrows:(r + 1) * maxrows].view(-1) for r in range(world)]
+            src = np.concatenate([r * maxrows + np.arange(len(self.rows[r]), dtype=np.int64) for r in range(world)])
+            dst = np.concatenate([np.asarray(self.rows[r], dtype=np.int64) for r in range(world)])
+            self.src_index = torch.as_tensor(src, device=device)
+            self.dst_index = torch.as_tensor(dst, device=device)
+        else:
+            self.recv_all, self.recv, self.src_index, self.dst_index = None, None, None, None
 
     @property
     def my_rows(self):
@@ -35,8 +45,6 @@ class BandGather:
     def assemble(self):
         """Rank 0: scatter the gathered bands into the (height, width, 3) frame."""
         assert self.rank == 0
-        for r in range(self.world):
-            n = len(self.rows[r])
-            if n:
-                self.frame[self.row_index[r]] = self.recv[r][: n * self.width * 3].view(n, self.width, 3)
+        if self.dst_index.numel():
+            self.frame.index_copy_(0, self.dst_index, self.recv_all.index_select(0, self.src_index))
         return self.frame
