@@ -95,11 +95,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    # rehearsal of the multi-rank path on a one-GPU box: RTX_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # gathers over gloo (RCCL wants one device per rank); never set by the driver, numbers are meaningless then
+    rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = rt.scenegen.WORKLOADS[args.workload]
     W = args.width or wl["width"]
@@ -121,6 +129,15 @@ def main():
     bands = importlib.import_module("rtxamd_pkg.bands")
     bg = bands.BandGather(W, H, args.band_rows if world > 1 else 0, world, rank, dev)
     assert len(bg.my_rows) == nrows
+    if rehearsal and world > 1:
+        def _gather_through_host(b=bg):  # gloo moves host tensors
+            send = b.send.cpu()
+            recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+            dist.gather(send, recv, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    b.recv[r].copy_(recv[r])
+        bg.gather = _gather_through_host
 
     def step():
         ctx.render(stream, bg.send.data_ptr())      # the band lands directly in the gather's send buffer
