@@ -327,9 +327,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->dalloc(&c->d_fimg, (size_t)ntrace * W * 3))) return rc;
     if ((rc = c->dalloc(&c->d_rgb8, (size_t)nown * W * 3))) return rc;
     if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels))) return rc;
-    if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels))) return rc;
-    if ((rc = c->dalloc(&c->d_tests, (size_t)8))) return rc;
-    if ((rc = c->dalloc(&c->d_pstat, (size_t)8))) return rc;
+    // frame totals, test counters and packet statistics in one block: one memset per frame
+    if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels + 16))) return rc;
+    c->d_tests = c->d_totals + 2 * levels;
+    c->d_pstat = c->d_tests + 8;
     c->S.pstat = (params->flags & RTX_F_PACKET_STATS) ? c->d_pstat : nullptr;
 
     // chunking: level k holds at most fanout^k rays per level-0 ray
@@ -414,10 +415,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     const int W = c->width, levels = c->levels;
     const int ntrace = (int)c->trace_rows.size(), nown = (int)c->own_rows.size();
     HIPCHK(hipEventRecord(c->ev0, st));
-    HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2 * levels, st));
-    HIPCHK(hipMemsetAsync(c->d_tests, 0, sizeof(unsigned long long) * 8, st));
-    HIPCHK(hipMemsetAsync(c->d_pstat, 0, sizeof(unsigned long long) * 8, st));
-    HIPCHK(hipMemsetAsync(c->d_scnt, 0, sizeof(int) * (size_t)std::max(c->nframe_chunks, 1) * levels, st));
+    HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * (2 * levels + 16), st));  // + d_tests, d_pstat
+    // (d_scnt needs no clearing: k_scan_sums writes a generation's queue size before its pass reads it)
     const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
     const bool exact_only = (c->params.flags & RTX_F_EXACT_ONLY) != 0;
     const bool timek = !c->kev.empty();
