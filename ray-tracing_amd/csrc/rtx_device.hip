@@ -86,10 +86,14 @@ struct rtx_context {
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
     unsigned long long* d_pstat = nullptr;
     // The shadow rays of generation k and the closest-hit pass of generation k+1 depend on nothing but
-    // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream k % kSide with
+    // k_setup(k): generation k's shadow chain (bin, scan, scatter, pass) runs on side stream side_of(k) with
     // that stream's own queue and scan buffers (fork after every set-up, one join per generation before
     // its own unwind), so the thin, latency-bound kernels of the deep generations overlap instead of queueing.
     static constexpr int kSide = 3;
+    // generation 0's pass is the long one (it ends last at every frame size measured): it keeps a stream to
+    // itself, the deeper generations alternate on the other two (generation 3 queued behind generation 0's
+    // pass cost a rank of 8 a tenth of its frame)
+    static int side_of(int k) { return k == 0 ? 0 : 1 + (k - 1) % (kSide - 1); }
     struct ShadowLane {
         hipStream_t stream = nullptr;
         ShadowQ q = {};
@@ -464,7 +468,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             } else if (c->S.nl > 0) {
                 // materialise and sort the shadow rays, then one any-hit pass -- on a side stream
-                rtx_context::ShadowLane& sl = c->side[k % rtx_context::kSide];
+                rtx_context::ShadowLane& sl = c->side[rtx_context::side_of(k)];
                 hipStream_t ss = sl.stream;
                 HIPCHK(hipEventRecord(c->ev_fork[k], st));
                 HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
