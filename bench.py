@@ -127,27 +127,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     import importlib
     bands = importlib.import_module("rtxamd_pkg.bands")
-    bg = bands.BandGather(W, H, args.band_rows if world > 1 else 0, world, rank, dev)
+    bg = bands.BandGather(W, H, args.band_rows if world > 1 else 0, world, rank, dev, via_host=rehearsal and world > 1)
     assert len(bg.my_rows) == nrows
-    if rehearsal and world > 1:
-        def _gather_through_host(b=bg):  # gloo moves host tensors
-            send = b.send.cpu()
-            recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-            dist.gather(send, recv, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    b.recv[r].copy_(recv[r])
-        bg.gather = _gather_through_host
 
     def step():
-        ctx.render(stream, bg.send.data_ptr())      # the band lands directly in the gather's send buffer
+        ctx.render(stream, bg.next_send().data_ptr())   # the band lands directly in the gather's send buffer
         if world > 1:
-            bg.gather()                             # RCCL over xGMI: the only cross-device step
-            if rank == 0:
-                bg.assemble()
+            # RCCL over xGMI, the only cross-device step: frame i's gather is on the wire while frame i+1 is
+            # traced; rank 0 assembles frame i-1 here.  Every timed frame is gathered and assembled before sync() returns.
+            bg.submit()
 
     def sync():
         if world > 1:
+            bg.flush()
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -39,6 +39,19 @@ def _worker(rank, world, port, W, H, band, out_path):
     if rank == 0:
         frame = bg.assemble().numpy()
         np.save(out_path, frame)
+    # the stream-of-frames path bench.py drives (submit / flush, two buffers in flight): frame i = the band
+    # with i added to every byte; each must come back whole and in order
+    got = []
+    for i in range(3):
+        bg.next_send()[: mine.size] = torch.from_numpy(((mine.astype(np.int32) + i) & 255).astype(np.uint8).reshape(-1))
+        f = bg.submit()
+        if rank == 0 and f is not None:
+            got.append(f.numpy().copy())
+    f = bg.flush()
+    if rank == 0:
+        got.append(f.numpy().copy())
+        assert bg.flush() is None
+        np.save(out_path + ".stream.npy", np.stack(got))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,3 +66,7 @@ def test_two_rank_band_gather_equals_single_frame(rt, oracle, tmp_path, band):
     sc = rt.load_scene(os.path.join(SCENES, "probe.txt"))
     ref, _ = oracle.render_rgb8(sc, W, H, 4)
     assert np.array_equal(frame, ref)
+    stream = np.load(out + ".stream.npy")
+    assert stream.shape[0] == 3
+    for i in range(3):
+        assert np.array_equal(stream[i], ((ref.astype(np.int32) + i) & 255).astype(np.uint8)), i
