@@ -98,7 +98,12 @@ struct rtx_context {
         hipStream_t stream = nullptr;
         ShadowQ q = {};
         int* hist = nullptr; int* offs = nullptr; int* rank = nullptr; int* bsum = nullptr; int* braw = nullptr;
-    } side[kSide];
+    } side[kSide + 1];
+    // The LAST generation's chain runs on the main stream itself, with the extra lane's buffers: after that
+    // generation's set-up the main stream has nothing left but the unwinds, which wait for the passes anyway,
+    // and the chain need not queue behind an earlier generation's pass (measured: 5.88 -> 5.81 ms per 4K frame,
+    // 1.36 -> 1.34 for a rank of 8; the last TWO generations there: slower, they delay the closest-hit chain).
+    int main_from = 1 << 30;
     std::vector<hipEvent_t> ev_fork, ev_pass;  // per generation: set-up done (main stream), shadow pass done (side stream)
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
@@ -337,13 +342,14 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->d_pstat = c->d_tests + 8;
     c->S.pstat = (params->flags & RTX_F_PACKET_STATS) ? c->d_pstat : nullptr;
 
+    if (levels >= 2) c->main_from = levels - 1;
     // chunking: level k holds at most fanout^k rays per level-0 ray
     const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
     double mult = 0, m = 1;
     for (int k = 0; k < levels; k++) { mult += m; m *= (c->fanout >= 2 ? 2.0 : 1.0); }
     uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
     // per level-0 ray: every level's slots, plus the side streams' shadow-ray queues (28 B a ray + 4 B rank) sized for the largest level
-    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * (double)std::min(levels, (int)rtx_context::kSide) * 32.0 * (double)c->S.nl);
+    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * (double)(std::min(levels, (int)rtx_context::kSide) + (levels >= 2 ? 1 : 0)) * 32.0 * (double)c->S.nl);
     int64_t rows = (int64_t)((double)budget / per_row);
     if (rows < 1) rows = 1;
     if (rows > ntrace) rows = ntrace;
@@ -379,8 +385,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
         const size_t maxbins = (size_t)c->nbins;
         const int nside = std::min(levels, (int)rtx_context::kSide);
-        for (int i = 0; i < nside; i++) {
-            rtx_context::ShadowLane& sl = c->side[i];
+        for (int i = 0; i <= nside; i++) {
+            if (i == nside && c->main_from >= levels) break;
+            rtx_context::ShadowLane& sl = c->side[i == nside ? (int)rtx_context::kSide : i];
             if ((rc = c->dalloc(&sl.q.a, qcap))) return rc;
             if ((rc = c->dalloc(&sl.q.b, qcap))) return rc;
             if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
@@ -468,11 +475,14 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back(1); }
             } else if (c->S.nl > 0) {
                 // materialise and sort the shadow rays, then one any-hit pass -- on a side stream
-                rtx_context::ShadowLane& sl = c->side[rtx_context::side_of(k)];
-                hipStream_t ss = sl.stream;
-                HIPCHK(hipEventRecord(c->ev_fork[k], st));
-                HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
-                forked[k] = true;
+                const bool on_main = k >= c->main_from;
+                rtx_context::ShadowLane& sl = c->side[on_main ? (int)rtx_context::kSide : rtx_context::side_of(k)];
+                hipStream_t ss = on_main ? st : sl.stream;
+                if (!on_main) {
+                    HIPCHK(hipEventRecord(c->ev_fork[k], st));
+                    HIPCHK(hipStreamWaitEvent(ss, c->ev_fork[k], 0));
+                    forked[k] = true;
+                }
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
                 HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
                 hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
@@ -489,7 +499,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
                 hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
-                HIPCHK(hipEventRecord(c->ev_pass[k], ss));
+                if (!on_main) HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }
             if (c->fanout >= 2) live_cap *= 2;
         }
