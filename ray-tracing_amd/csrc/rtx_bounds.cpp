@@ -278,4 +278,43 @@ BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard)
     return make(c, Rs + eta);
 }
 
+// Edge filter.  The exact test (raytracing.cpp:338-365) computes P = o + dir*t and vec1 = P - v in binary32
+// and accepts only if the three sub-areas exceed the area by <= tau = 0.01 + delta in real arithmetic (delta:
+// the binary32 error of the four areas, as above, here for every P with |P - v| <= Q).  Each sub-area is at
+// least its projection on the triangle's plane, A |b_i| with b_i the barycentric coordinates of P's
+// projection, and sum b_i = 1, so the excess is >= 2 A sum_{b_i < 0} |b_i|: an accepted P has every
+// b_i >= -tau / (2 A).  The kernel evaluates b_1 = a1 . vec1 (weight of u), b_2 = a2 . vec1 (weight of w)
+// with the in-plane dual vectors a1, a2 of the edges u - v, w - v and b_0 = (1 - b_1) - b_2, from the SAME
+// binary32 vec1 the exact test goes on to use, and rejects when |vec1|_1 <= Q and some b_i < -m (-2m for b_0).
+// Its own error: a_i rounded to binary32 (u |a|_inf |p|_1), vec1 rounded (the same), the dot product
+// (3u |a|_inf |p|_1): < 8u amax Q for |p|_1 <= Q; b_0 adds both plus 4u (1 + |b_1| + |b_2|).  With
+// m = tau / (2A) + 32u amax Q + 1e-6 all of that is covered.  Anything not covered (degenerate or huge
+// triangles, non-finite numbers) gets Q = -1 and is never rejected; NaN compares false and is never rejected.
+TriEdge tri_edge_filter(const rtx_triangle& t)
+{
+    const TriEdge never = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, -1.0f};
+    D3 u = d3(t.u), v = d3(t.v), w = d3(t.w);
+    if (!finite3(u) || !finite3(v) || !finite3(w)) return never;
+    D3 e1 = u - v, e2 = w - v;
+    D3 n = cross(e1, e2);
+    double nn2 = dot(n, n);
+    double A = 0.5 * std::sqrt(nn2);
+    double l[3] = {norm(w - v), norm(u - w), norm(v - u)};
+    double emax = std::max(l[0], std::max(l[1], l[2])), emin = std::min(l[0], std::min(l[1], l[2]));
+    if (!(emin > 1e-6 * emax) || !(A > 1e-7 * emax * emax) || !(emax < 1e8) || !(emax > 1e-8)) return never;
+    const double uu = 1.0 / 16777216.0;
+    double Q = 32.0 * emax;
+    double delta = (Q + emax) * emax * (64.0 * uu) + A * (16.0 * uu);
+    double tau = (0.01 + delta) * 1.001;
+    D3 a1 = cross(e2, n) * (1.0 / nn2);
+    D3 a2 = cross(n, e1) * (1.0 / nn2);
+    double amax = 0;
+    for (double c : {a1.x, a1.y, a1.z, a2.x, a2.y, a2.z}) amax = std::max(amax, std::fabs(c));
+    double m = tau / (2.0 * A) * (1.0 + 1e-6) + 32.0 * uu * amax * Q + 1e-6;
+    if (!std::isfinite(m) || !(m < 1e30) || !(amax < 1e30)) return never;
+    float Qf = (float)(Q * (1.0 - 1e-6));
+    if ((double)Qf > Q) return never;
+    return {(float)a1.x, (float)a1.y, (float)a1.z, up(m), (float)a2.x, (float)a2.y, (float)a2.z, Qf};
+}
+
 }  // namespace rtx

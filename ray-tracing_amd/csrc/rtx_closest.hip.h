@@ -113,8 +113,9 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
         }
     } else if (k < S.ns + S.nt) {
         TriRec T = load_tri(S.tri_hot, k - S.ns);
+        const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
         float t, vd;
-        if (triangle_test(o, d, T, t, vd)) {
+        if (triangle_test_edge(o, d, T, e0, e1, t, vd, h.nearest)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
     } else {

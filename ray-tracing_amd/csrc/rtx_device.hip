@@ -207,6 +207,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((rc = c->dalloc(&thot, P.tri_hot.size() * 5))) return rc;
         if (!P.tri_hot.empty()) HIPCHK(hipMemcpy(thot, P.tri_hot.data(), P.tri_hot.size() * sizeof(TriHot), hipMemcpyHostToDevice));
         c->S.tri_hot = thot;
+        float4* tedge = nullptr;
+        static_assert(sizeof(TriEdge) == 2 * sizeof(float4), "triangle edge record is two float4");
+        if ((rc = c->dalloc(&tedge, P.tri_edge.size() * 2))) return rc;
+        if (!P.tri_edge.empty()) HIPCHK(hipMemcpy(tedge, P.tri_edge.data(), P.tri_edge.size() * sizeof(TriEdge), hipMemcpyHostToDevice));
+        c->S.tri_edge = tedge;
         float4* ph = nullptr;
         if ((rc = c->dalloc(&ph, P.prim_hot.size() * 5))) return rc;
         if (!P.prim_hot.empty()) HIPCHK(hipMemcpy(ph, P.prim_hot.data(), P.prim_hot.size() * sizeof(TriHot), hipMemcpyHostToDevice));

@@ -23,6 +23,7 @@ struct SceneDev {
     const rtx_xmatrix* sph_im;    // [ns]  precomputed inverseMatrix(mat)
     const rtx_sphere* sph;        // [ns]
     const float4* tri_hot;        // [nt*5]
+    const float4* tri_edge;       // [nt*2] edge filter { a1, m }, { a2, Q } (rtx_bounds.cpp, tri_edge_filter)
     const float4* phot;           // [(ns+nt)*5] one 80-byte hot record per primitive (rtx_pack.h, prim_hot)
     const rtx_triangle* tri;      // [nt]
     const rtx_light* lights;      // [nl]

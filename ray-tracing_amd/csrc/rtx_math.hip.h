@@ -128,6 +128,39 @@ __device__ __forceinline__ bool triangle_test(F3 o, F3 dir, const TriRec& T, flo
     return true;
 }
 
+// The same test with the edge filter (rtx_bounds.cpp, tri_edge_filter) between the plane intersection and the
+// area square roots: e0 = { a1, m }, e1 = { a2, Q }.  Returns exactly what triangle_test returns.
+// tmax: a closest-hit caller that only takes hits with t < nearest passes nearest, and a hit it would drop
+// is reported as a miss before the areas are computed (any-hit callers pass +inf: NaN and every t stay in).
+__device__ __forceinline__ bool triangle_test_edge(F3 o, F3 dir, const TriRec& T, const float4 e0, const float4 e1, float& t, float& vd,
+                                                   const float tmax = __builtin_inff())
+{
+    vd = T.nx * dir.x + T.ny * dir.y + T.nz * dir.z;
+    if (vd == 0.0f) return false;
+    t = -((T.nx * o.x + T.ny * o.y + T.nz * o.z) + T.d) / vd;
+    if (t < 0.0f) return false;
+    if (t >= tmax) return false;
+    float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+    float ax = px - T.vx, ay = py - T.vy, az = pz - T.vz;  // vec1
+    {
+        const float q = fabsf(ax) + fabsf(ay) + fabsf(az);
+        const float b1 = e0.x * ax + e0.y * ay + e0.z * az;
+        const float b2 = e1.x * ax + e1.y * ay + e1.z * az;
+        const float b0 = (1.0f - b1) - b2;
+        const float nm = -e0.w;
+        if (q <= e1.w && (b1 < nm || b2 < nm || b0 < nm + nm)) return false;
+    }
+    float bx = px - T.wx, by = py - T.wy, bz = pz - T.wz;  // vec2
+    float c1x = ay * T.v1z - T.v1y * az, c1y = T.v1x * az - T.v1z * ax, c1z = T.v1y * ax - T.v1x * ay;
+    float c2x = az * T.v2y - ay * T.v2z, c2y = ax * T.v2z - az * T.v2x, c2z = ay * T.v2x - ax * T.v2y;
+    float c3x = bz * T.ey - by * T.ez, c3y = bx * T.ez - bz * T.ex, c3z = by * T.ex - bx * T.ey;
+    float areau = 0.5f * sqrtf(c2x * c2x + c2y * c2y + c2z * c2z);
+    float areav = 0.5f * sqrtf(c3x * c3x + c3y * c3y + c3z * c3z);
+    float areaw = 0.5f * sqrtf(c1x * c1x + c1y * c1y + c1z * c1z);
+    if (fabsf(areau + areav + areaw - T.area) > 0.01f) return false;
+    return true;
+}
+
 // x*x*x rounded once (error-free products; the tail sum is far below half an ulp), standing in
 // for glibc's pow(x, 3.0) (raytracing.cpp:465) which is correctly rounded in all but
 // vanishingly rare cases; the result is rounded to float right after (see fresnel_term).

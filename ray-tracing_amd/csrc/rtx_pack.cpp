@@ -218,6 +218,7 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
                        v1.y, v1.z, v2.x, v2.y,
                        v2.z, e.x, e.y, e.z } };
         P.tri_hot.push_back(h);
+        P.tri_edge.push_back(tri_edge_filter(t));
         P.tri.push_back(t);
         int f = (t.reflectivity > 0 ? 1 : 0) + (t.transparency > 0 ? 1 : 0);
         if (f > fan) fan = f;

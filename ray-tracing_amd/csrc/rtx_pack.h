@@ -36,6 +36,11 @@ BoundSphere bound_sphere_plain(const rtx_sphere& s);
 BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, double guard);
 BoundSphere bound_sphere_triangle(const rtx_triangle& t, double guard);
 
+// Edge filter of a triangle (rtx_bounds.cpp): barycentric coordinates of the reference's own point P with a
+// certified margin, run between the plane intersection and the three area square roots of the exact test.
+struct TriEdge { float a1x, a1y, a1z, m, a2x, a2y, a2z, Q; };
+TriEdge tri_edge_filter(const rtx_triangle& t);
+
 // 64-byte filter record of one affine sphere for SHADOW rays (raytracing.cpp:571-576: the
 // direction is inverse-transformed, the origin is not): rows of the inverse's linear part, the
 // centre, -R^2 (inflated; -inf = always pass), the sphere's index, and for the shadow kernel's packet test R and ||A||_F, both rounded up.
@@ -89,6 +94,7 @@ struct PackedScene {
                                          // `transformed` flag quirk, :396-399, :443, :454)
     std::vector<rtx_sphere>  sph;        // raw records (materials, centre, radius, mat)
     std::vector<TriHot>      tri_hot;
+    std::vector<TriEdge>     tri_edge;   // [ntriangles]
     // one 80-byte record per primitive (spheres first), fetched by the lanes that need it with five
     // independent 16-byte loads: sphere { c, r*r | im.a, im.b.x | im.b.yz, im.c.xy | im.c.z, im.d | xf, 0, 0, 0 },
     // triangle = its TriHot

@@ -16,8 +16,9 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
         return sphere_test(o, td, hh.x, hh.y, hh.z, hh.w, t);
     }
     TriRec T = load_tri(S.tri_hot, k - S.ns);
+    const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
     float t, vd;
-    return triangle_test(o, ld, T, t, vd);
+    return triangle_test_edge(o, ld, T, e0, e1, t, vd);
 }
 
 // Shadow rays (raytracing.cpp:560-589) are any-hit: which primitive blocks the light first does not
