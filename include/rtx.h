@@ -221,6 +221,12 @@ int  rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out);
  * may be NULL to query it. */
 int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t capacity);
 
+/* The triangles' edge-filter records (8 floats each: a1.xyz, m, a2.xyz, Q; rtx_bounds.cpp): between the plane
+ * intersection and the area square roots of raytracing.cpp:338-365 the kernels reject a point P with
+ * |P - v|_1 <= Q whose barycentric coordinate a1.(P - v), a2.(P - v) or 1 - both is below -m (-2m for the
+ * third).  Q = -1: never rejected.  Exported so the CPU suite can check that bound against the reference's test. */
+int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8);
+
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),
  * records zero-filled before parsing.  Polygons keep parseinput's rules: normal from the

@@ -374,3 +374,14 @@ extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, i
     }
     return n;
 }
+
+extern "C" int rtx_triangle_edge_records(const rtx_scene* scene, float* out8)
+{
+    if (!scene || !out8 || (scene->ntriangles && !scene->triangles)) return RTX_E_INVALID_ARG;
+    static_assert(sizeof(rtx::TriEdge) == 32, "8 floats");
+    for (int i = 0; i < scene->ntriangles; i++) {
+        const rtx::TriEdge e = rtx::tri_edge_filter(scene->triangles[i]);
+        std::memcpy(out8 + (size_t)8 * i, &e, sizeof(e));
+    }
+    return RTX_OK;
+}

@@ -119,6 +119,7 @@ SYMBOLS = {
     "rtx_band_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.POINTER(C.c_float)]),
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
+    "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
     "rtx_write_ppm": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -223,6 +224,13 @@ def filter_records(scene):
     g = C.c_float()
     _check(lib().rtx_filter_records(scene.ptr, out.ctypes.data, C.byref(g)), "rtx_filter_records")
     return out, g.value
+
+
+def triangle_edge_records(scene):
+    """records[ntriangles,8] float32: a1.xyz, m, a2.xyz, Q (rtx_triangle_edge_records)."""
+    out = np.zeros((scene.view.ntriangles, 8), dtype=np.float32)
+    _check(lib().rtx_triangle_edge_records(scene.ptr, out.ctypes.data), "rtx_triangle_edge_records")
+    return out
 
 
 def affine_shadow_records(scene):

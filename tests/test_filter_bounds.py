@@ -235,3 +235,112 @@ def test_direction_cell_chord_bound():
         v /= np.linalg.norm(v, axis=1, keepdims=True)
         chord = np.linalg.norm(d.astype(np.float64) - v, axis=1)
         assert chord.max() <= 4.2427 / G + 1e-5, (G, chord.max() * G)
+
+
+def edge_filter_reject(sc, erec, o, d):
+    """The kernel's edge filter (triangle_test_edge, rtx_math.hip.h) in binary32, one operation per operator:
+    reject[ray, triangle].  The plane intersection is the reference's own (raytracing.cpp:330-352)."""
+    v = sc.view
+    n_t = v.ntriangles
+    rej = np.zeros((o.shape[0], n_t), dtype=bool)
+    ox, oy, oz = (o[:, k] for k in range(3))
+    dx, dy, dz = (d[:, k] for k in range(3))
+    with np.errstate(all="ignore"):
+        for i in range(n_t):
+            t = v.triangles[i]
+            U, V, Wv = ([f32(p.x), f32(p.y), f32(p.z)] for p in (t.u, t.v, t.w))
+            v1 = [U[k] - V[k] for k in range(3)]
+            v2 = [Wv[k] - V[k] for k in range(3)]
+            n = [v1[1] * v2[2] - v2[1] * v1[2], v2[0] * v1[2] - v1[0] * v2[2], v1[0] * v2[1] - v2[0] * v1[1]]
+            norm = np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+            if norm > 0:
+                n = [c / norm for c in n]
+            dd = -(n[0] * U[0] + n[1] * U[1] + n[2] * U[2])
+            vd = n[0] * dx + n[1] * dy + n[2] * dz
+            tt = -((n[0] * ox + n[1] * oy + n[2] * oz) + dd) / vd
+            ax = (ox + dx * tt) - V[0]
+            ay = (oy + dy * tt) - V[1]
+            az = (oz + dz * tt) - V[2]
+            e = erec[i]
+            q = np.abs(ax) + np.abs(ay) + np.abs(az)
+            b1 = e[0] * ax + e[1] * ay + e[2] * az
+            b2 = e[4] * ax + e[5] * ay + e[6] * az
+            b0 = (f32(1.0) - b1) - b2
+            nm = -e[3]
+            rej[:, i] = (q <= e[7]) & ((b1 < nm) | (b2 < nm) | (b0 < nm + nm))
+    return rej
+
+
+def edge_rays(sc, rng, n_per_tri):
+    """Rays through points on, just inside and just outside every triangle's edges and vertices (the band the
+    reference's 0.01 area tolerance accepts is 0.01 / edge length wide), head-on and grazing."""
+    v = sc.view
+    T, N = [], []
+    for i in range(v.ntriangles):
+        t = v.triangles[i]
+        A, B, Cc = (np.array([p.x, p.y, p.z], dtype=np.float64) for p in (t.u, t.v, t.w))
+        w = rng.dirichlet([1.0, 1.0, 1.0], size=n_per_tri)
+        w[: n_per_tri // 2, rng.integers(0, 3)] = 0.0                     # on an edge line
+        w[: n_per_tri // 2] /= np.maximum(w[: n_per_tri // 2].sum(axis=1, keepdims=True), 1e-9)
+        P = w[:, :1] * A + w[:, 1:2] * B + w[:, 2:] * Cc
+        nn = np.cross(B - A, Cc - A)
+        ln = np.linalg.norm(nn)
+        nn = nn / ln if ln > 0 else np.array([0.0, 0.0, 1.0])
+        c = (A + B + Cc) / 3.0
+        out = P - c
+        out /= np.maximum(np.linalg.norm(out, axis=1, keepdims=True), 1e-12)
+        emax = max(np.linalg.norm(B - A), np.linalg.norm(Cc - A), np.linalg.norm(Cc - B), 1e-6)
+        P = P + out * rng.choice([0.0, 1e-4, 1e-3, 3e-3, 1e-2, 3e-2, 0.1, 1.0], size=(n_per_tri, 1)) / emax * rng.choice([-1.0, 1.0, 1.0], size=(n_per_tri, 1))
+        T.append(P)
+        N.append(np.tile(nn, (n_per_tri, 1)))
+    T, N = np.concatenate(T), np.concatenate(N)
+    side = rng.normal(size=T.shape)
+    tilt = rng.choice([0.0, 0.3, 3.0, 30.0, 300.0], size=(T.shape[0], 1))   # up to grazing incidence
+    dirn = N * rng.choice([-1.0, 1.0], size=(T.shape[0], 1)) + side * tilt
+    dirn /= np.maximum(np.linalg.norm(dirn, axis=1, keepdims=True), 1e-30)
+    o = T - dirn * rng.choice([0.01, 1.0, 30.0, 300.0], size=(T.shape[0], 1))
+    d = (T - o)
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    o32 = o.astype(f32)
+    d32 = d.astype(f32)
+    d32 /= np.sqrt((d32 * d32).sum(axis=1, keepdims=True)).astype(f32)
+    return o32, d32.astype(f32)
+
+
+@pytest.mark.parametrize("edge", [0.3, 2.0, 12.0])
+def test_triangle_edge_filter_never_rejects_an_accepted_pair(rt, oracle, tmp_path, edge):
+    p = str(tmp_path / "tris.txt")
+    rt.scenegen.write_scene(p, 4, 120, [(0.0, 40.0, 10.0, 0.3, 0.3, 0.3)], seed=77, edge=edge)
+    sc = rt.load_scene(p)
+    erec = rt.triangle_edge_records(sc)
+    ns, nt = sc.view.nspheres, sc.view.ntriangles
+    assert erec.shape == (nt, 8) and (erec[:, 7] > 0).all() and (erec[:, 3] > 0).all()
+    rng = np.random.default_rng(11)
+    o, d = edge_rays(sc, rng, 300)
+    acc = oracle.accept_matrix(sc, o, d).astype(bool)[:, ns:ns + nt]
+    rej = edge_filter_reject(sc, erec, o, d)
+    assert acc.sum() > 5000, "test rays do not exercise the triangles"
+    viol = acc & rej
+    assert not viol.any(), "edge filter rejected %d accepted pairs, triangles %s" % (viol.sum(), np.unique(np.argwhere(viol)[:, 1]))
+    # and it is a filter: of the rays aimed at a triangle's own neighbourhood that the reference rejects, most are cut
+    own = np.zeros_like(acc)
+    for i in range(nt):
+        own[i * 300:(i + 1) * 300, i] = True
+    assert rej[own & ~acc].mean() > 0.25   # (the rest: t < 0, hits inside the certified margin, grazing hits beyond Q)
+
+
+def test_triangle_edge_filter_degenerate_never_rejects(rt, tmp_path):
+    """Zero-area and non-finite triangles get Q = -1 (no point has |P - v|_1 <= -1)."""
+    p = str(tmp_path / "deg.txt")
+    with open(p, "w") as f:
+        f.write("camera 0 0 -1\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0.05 0.05 0.05\n")
+        mat = " 0.5 0.5 0.5  0.5 0.5 0.5  0.5 0.5 0.5  10  0 0 1.2"
+        f.write("triangle 0 0 -5  1 0 -5  2 0 -5" + mat + "\n")          # collinear
+        f.write("triangle 0 0 -5  0 0 -5  0 0 -5" + mat + "\n")          # a point
+        f.write("triangle 0 0 -5  1e-9 0 -5  0 1 -5" + mat + "\n")       # one edge 1e-9 of the others
+        f.write("triangle 0 0 -5  1 0 -5  0 1 -5" + mat + "\n")          # a proper one
+    sc = rt.load_scene(p)
+    erec = rt.triangle_edge_records(sc)
+    assert erec.shape == (sc.view.ntriangles, 8) and np.isfinite(erec).all()
+    if sc.view.ntriangles == 4:
+        assert (erec[:3, 7] == -1.0).all() and erec[3, 7] > 0
