@@ -104,6 +104,7 @@ struct rtx_context {
     // and the chain need not queue behind an earlier generation's pass (measured: 5.88 -> 5.81 ms per 4K frame,
     // 1.36 -> 1.34 for a rank of 8; the last TWO generations there: slower, they delay the closest-hit chain).
     int main_from = 1 << 30;
+    int split4 = kSplitRays, split8 = kSplitRays8;  // shadow generations up to this many rays: 4 / 8 workgroups per 256 rays
     std::vector<hipEvent_t> ev_fork, ev_pass;  // per generation: set-up done (main stream), shadow pass done (side stream)
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
@@ -499,10 +500,10 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 }
                 hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
-                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)kSplitRays)) * kSplit));
-                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)kSplitRays8)) * 2 * kSplit));
+                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split4)) * kSplit));
+                gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split8)) * 2 * kSplit));
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
-                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap);
+                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
                 if (!on_main) HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }

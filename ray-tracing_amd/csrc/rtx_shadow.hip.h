@@ -535,13 +535,13 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
 // and the serial walk per wave -- what bounds the run time when there are fewer waves than SIMDs can hold --
 // is kSplit times shorter.
 constexpr int kSplit = 4;
-constexpr int kSplitRays = 1 << 21;
-constexpr int kSplitRays8 = 1 << 19;  // ... and by 2 * kSplit workgroups below this
+constexpr int kSplitRays = 1 << 20;   // (re-measured after the edge filter: 2^21 / 2^19 cost 2 ranks 7 %, 8 ranks 4 % of their frame)
+constexpr int kSplitRays8 = 1 << 17;  // ... and by 2 * kSplit workgroups below this
 
-__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
+__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
-    const int parts = (n <= kSplitRays8) ? 2 * kSplit : (n <= kSplitRays) ? kSplit : 1;
+    const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
     __shared__ unsigned short alist[kBlock / 64][kAffListCap];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
