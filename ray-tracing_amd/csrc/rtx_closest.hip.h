@@ -369,7 +369,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if constexpr (PREFETCH) {
         // Walk the bitmap in index order: file order, as the reference's loops (:385-418).
-        // Few waves per SIMD (frames below ~4 M rays): a wave's serial chain of dependent loads IS the run time.
+        // Few waves per SIMD (frames below ~1 M rays): a wave's serial chain of dependent loads IS the run time.
         // The set bits of 32 words are first written out as a list (wave-level prefix sum of the popcounts keeps
         // the order), then 64 candidates at a time fetch their filter record and hot record with independent
         // loads -- one memory round trip for the lot -- and the ordered loop reads them from registers.
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 // generation has fewer waves than the chip has SIMDs, its run time is one wave's serial walk, and the pooled
 // stages keep all 64 lanes busy whatever the number of rays.
 constexpr int kSplitClosest = 1 << 17;
-constexpr size_t kPrefetchRays = (size_t)1 << 22;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
+constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
 {
