@@ -235,6 +235,25 @@ def main():
                     roof["traffic"] = (2.0 * fetch_kb + write_kb) * 1024.0
                     roof["traffic_note"] = ("bytes per launch from %s (FETCH_SIZE x 2 + WRITE_SIZE, KB): an upper bound, against "
                                             "%.3g algorithmic FLOPs per launch" % (os.path.basename(files[-1]), roof.get("flops_per_frame", 0.0) / max(n_dom, 1)))
+        # executed side, whole frame: wave-level VALU instructions (same counter passes) / the live frame time, against
+        # the issue rate the nominal FP32 peak implies (157.3 TFLOP/s = 2 FLOPs x 64 lanes x 1,229 G wave-instructions/s)
+        if args.workload == "c4" and not (args.width or args.height) and world == 1 and files:
+            tot, frames = 0.0, None
+            for row in csv.DictReader(open(files[-1])):
+                name = row["kernel"].replace("rtx::", "")
+                if name.startswith("k_affine_cells"):
+                    continue                      # context creation, not the frame
+                if name.startswith("k_raygen"):
+                    frames = float(row["dispatches_per_pass"])   # one launch per frame
+                tot += float(row.get("SQ_INSTS_VALU", 0.0) or 0.0)
+            if frames and tot:
+                per_frame = tot / frames
+                rate = per_frame / (st.ms_total * 1e-3) / 1e9
+                peak_issue = PEAK_FP32_TFLOPS * 1e12 / 128.0 / 1e9
+                roof["valu_issue"] = {"wave_instr_per_frame": per_frame, "G_instr_per_s": rate, "peak_G_instr_per_s": peak_issue,
+                                      "frac": rate / peak_issue, "source": os.path.basename(files[-1]),
+                                      "note": "SQ_INSTS_VALU summed over the frame's kernels (counter passes over the same frame, "
+                                              "committed) / this run's frame time; active lanes per instruction: DESIGN.md 4.5"}
         out["roofline"] = roof
     # ---- end to end at the C-ABI: untimed extras, N = 1 only ----
     if rank == 0 and world == 1:
