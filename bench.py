@@ -11,12 +11,14 @@ gather (torch.distributed, backend nccl).  The frame is FIXED as N grows (strong
 value = rays actually traced (primary + reflection/refraction + shadow) per second, whole job.
 
 The JSON line also carries
-  roofline     for the dominant kernel (k_shadow_pass, k_closest_lanes or k_closest_f, whichever took
-               longest): ALGORITHMIC FLOPs of the ray x primitive tests the reference's loops run for
-               the rays that kernel traces (20 / 65 / 76 / 13 FLOP per sphere / affine
-               sphere / triangle / early-exit triangle test, counted by the exact counting kernels in
-               a separate untimed frame) / its launch time, measured with HIP events on the kernel's
-               own stream during the timed steps.  The bound is FP32 VALU, not HBM or MFMA.
+  roofline     for the dominant kernel (k_shadow_pass, k_closest_lanes or k_closest_f, whichever takes longest):
+               achieved = the FLOPs of the tests that kernel EXECUTES (per-kind counters of the production kernels'
+               counting instantiations, RTX_F_COUNT_EXEC, x the per-test figures EXEC_FLOPS below: SURVEY.md 8d for the
+               reference's tests, counted the same way for the hierarchy tests in front of them) / its summed launch
+               time in a SERIAL frame (RTX_F_SERIAL: one stream, nothing overlaps; HIP events on that stream), so
+               frac <= 1 by construction.  The bound is FP32 VALU, not HBM or MFMA.  Beside it, never as a fraction of
+               peak: algorithmic_equiv (what the reference's brute-force loops would execute for the same rays) and
+               culling_factor = algorithmic / executed; and brute_force_kernel, the exact-only kernels' own fraction.
   cpu_baseline the reference renderer itself (oracle/_ref/rt_ref, compiled from the reference's
                source in the build container) or, if that binary is absent, this repo's scalar
                C port (oracle/), timed on ONE host core on a small image of the same scene.
@@ -35,6 +37,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_TEST = (20.0, 65.0, 76.0, 13.0)  # sphere, affine sphere, triangle, triangle early exit
+# FLOPs per EXECUTED test of the production kernels (add/sub/mul/div/sqrt/neg = 1, FMA = 2, compare/select/abs = 0),
+# by rtx_stats.exec_counts kind; the exact tests carry SURVEY.md 8d's figures, the hierarchy tests are counted the
+# same way from their source (DESIGN.md 4.5 lists the operations)
+EXEC_FLOPS = {"packet": 28.0, "cone": 25.0, "filt": 16.0, "afilt": 39.0, "strip": 150.0,
+              "sph": 20.0, "sphx": 65.0, "tri_early": 13.0, "tri_cull": 13.0, "tri_edge": 38.0, "tri_full": 76.0,
+              "poly": 30.0, "packets_built": 0.0, "rays": 0.0}
 PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
 PEAK_FP32_NOFMA_TFLOPS = 78.65            # contraction is off for parity: one FLOP per lane-op
 
@@ -72,18 +80,171 @@ def cpu_baseline(scene_path, scene, max_depth, seconds_target=20.0):
                        "%d rays in %.1f s" % (w, h, rays, dt))
 
 
-def main():
+def pmc_summary(workload):
+    """Per-kernel rows of the newest committed counter passes over this workload's frame (tools/pmc_passes.sh)."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.csv" % workload)))
+    if not files:
+        return None, []
+    return os.path.basename(files[-1]), list(csv.DictReader(open(files[-1])))
+
+
+def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
+    F = rt.host
+    full = not (args.width or args.height) and world == 1
+    roof = {"bound": "valu-fp32", "kernel": None, "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
+            "traffic": None, "peak_no_fma": PEAK_FP32_NOFMA_TFLOPS, "frac_no_fma": None}
+    if args.no_count:
+        return roof
+    # (a) executed work, by kernel and kind (untimed frame, counting instantiations of the production kernels)
+    c = make_ctx(F.F_COUNT_EXEC)
+    c.render(stream, None)
+    ex = c.stats().exec_dict()
+    c.close()
+    # (b) non-overlapped kernel times: serial frames, HIP events around every hot launch
+    c = make_ctx(F.F_SERIAL | F.F_TIME_KERNELS)
+    for _ in range(3):
+        c.render(stream, None)
+    ss = c.stats()
+    c.close()
+    ms = {"k_closest_f": (ss.ms_closest, ss.launches_closest), "k_closest_lanes": (ss.ms_closest_lanes, ss.launches_closest_lanes),
+          "k_shadow_pass": (ss.ms_shadow, ss.launches_shadow)}
+    per = {}
+    for kn in F.EXEC_KERNELS:
+        fl = sum(ex[kn][kd] * EXEC_FLOPS[kd] for kd in ex[kn])
+        t, n = ms[kn]
+        ach = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        per[kn] = {"ms_serial": t, "launches": n, "executed_flops": fl, "achieved": ach, "frac": ach / PEAK_FP32_TFLOPS,
+                   "frac_no_fma": ach / PEAK_FP32_NOFMA_TFLOPS, "executed_tests": {k: v for k, v in ex[kn].items() if v}}
+    dom = max(per, key=lambda k: per[k]["ms_serial"])
+    d = per[dom]
+    tot_fl = sum(v["executed_flops"] for v in per.values())
+    roof.update(kernel=dom, achieved=d["achieved"], frac=d["frac"], frac_no_fma=d["frac_no_fma"],
+                launches_per_frame=d["launches"], avg_launch_ms=d["ms_serial"] / max(d["launches"], 1),
+                executed_flops_per_launch=d["executed_flops"] / max(d["launches"], 1),
+                per_kernel=per,
+                frame={"ms_serial": ss.ms_total, "ms_overlapped": st_timed.ms_total, "executed_flops": tot_fl,
+                       "achieved": tot_fl / (st_timed.ms_total * 1e-3) / 1e12,
+                       "frac": tot_fl / (st_timed.ms_total * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+                flops_per_test=EXEC_FLOPS,
+                note="achieved = FLOPs of the tests this kernel EXECUTES (rtx_stats.exec_counts of a counting frame x flops_per_test) "
+                     "/ its summed launch time in a serial frame (RTX_F_SERIAL, HIP events; nothing overlaps); frame.* = the three "
+                     "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.")
+    # (c) what the reference's brute-force loops would execute for the same rays, and the exact-only kernels' own fraction
+    bw, bh = (W, H) if args.workload != "c5" else (W // 16, H // 16)   # C5 brute force at full size is minutes per frame
+    import rtxamd as rt_
+    def mk(flags):
+        return rt_.Context(make_ctx.scene, rt_.Params.make(bw, bh, wl["max_depth"], device=make_ctx.device, flags=flags))
+    c = mk(F.F_COUNT_TESTS)
+    c.render(stream, None)
+    cs = c.stats()
+    c.close()
+    alg_c = sum(float(cs.tests_closest_kind[k]) * FLOP_PER_TEST[k] for k in range(4))
+    alg_s = sum(float(cs.tests_shadow_kind[k]) * FLOP_PER_TEST[k] for k in range(4))
+    c = mk(F.F_EXACT_ONLY | F.F_SERIAL | F.F_TIME_KERNELS)
+    c.render(stream, None)
+    c.render(stream, None)
+    bs = c.stats()
+    c.close()
+    scale = (W * H) / float(bw * bh)
+    roof["algorithmic_equiv"] = {"flops_per_frame": (alg_c + alg_s) * scale, "closest_flops": alg_c * scale, "shadow_flops": alg_s * scale,
+                                 "note": "the reference's loops for the same rays (every primitive in file order, shadow rays leaving at their "
+                                         "first blocker), SURVEY.md 8d FLOPs per test; NOT executed by the timed kernels"
+                                         + ("; counted on a %dx%d frame and scaled by the pixel ratio" % (bw, bh) if scale != 1.0 else "")}
+    roof["culling_factor"] = (alg_c + alg_s) * scale / max(tot_fl, 1.0)
+    bk = {}
+    for name, fl, t in (("k_shadow<false>", alg_s, bs.ms_shadow), ("k_closest<false>", alg_c, bs.ms_closest)):
+        a = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        bk[name] = {"ms": t, "flops": fl, "achieved": a, "frac": a / PEAK_FP32_TFLOPS, "frac_no_fma": a / PEAK_FP32_NOFMA_TFLOPS}
+    roof["brute_force_kernel"] = dict(bk, frame="%dx%d" % (bw, bh),
+                                      note="RTX_F_EXACT_ONLY: the reference's loops as written (all primitives, exact tests only), "
+                                           "serial frame; its executed FLOPs ARE the algorithmic FLOPs")
+    # (d) counters that cannot be collected inside this run (separate rocprofv3 --pmc passes, tools/pmc_passes.sh):
+    # taken from the newest committed passes over the same frame
+    if full:
+        src, rows = pmc_summary(args.workload)
+        frames, tot_valu = None, 0.0
+        for row in rows:
+            name = row["kernel"].replace("rtx::", "")
+            if name.startswith("k_affine_cells"):
+                continue
+            if name.startswith("k_raygen"):
+                frames = float(row["dispatches_per_pass"])
+            tot_valu += float(row.get("SQ_INSTS_VALU", 0.0) or 0.0)
+            if name.split("<")[0] == dom:
+                launches = max(float(row["dispatches_per_pass"]), 1.0)
+                g = lambda k: float(row.get(k, 0.0) or 0.0)
+                if g("FETCH_SIZE") or g("WRITE_SIZE"):
+                    # the guide's gfx950 correction: FETCH_SIZE tallies wide (16 B / lane) reads at half their bytes; the
+                    # kernel mixes widths, so the doubled figure is an upper bound
+                    roof["traffic"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 / launches
+                    roof["traffic_note"] = "HBM bytes per launch from %s (FETCH_SIZE x 2 + WRITE_SIZE, KB): an upper bound" % src
+                if g("SQ_INSTS_VALU"):
+                    roof["active_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_ACTIVE_INST_VALU") * 64.0, 1.0) if g("SQ_ACTIVE_INST_VALU") else None
+                    roof["salu_per_valu"] = g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU")
+                if g("SQ_BUSY_CYCLES"):
+                    roof["occupancy_waves_per_simd"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES") / 4.0 if g("SQ_WAVE_CYCLES") else None
+                roof["pmc_source"] = src
+        if frames and tot_valu:
+            per_frame = tot_valu / frames
+            rate = per_frame / (st_timed.ms_total * 1e-3) / 1e9
+            peak_issue = PEAK_FP32_TFLOPS * 1e12 / 128.0 / 1e9
+            roof["valu_issue"] = {"wave_instr_per_frame": per_frame, "G_instr_per_s": rate, "peak_G_instr_per_s": peak_issue,
+                                  "frac": rate / peak_issue, "source": src,
+                                  "note": "SQ_INSTS_VALU summed over the frame's kernels (committed counter passes over the same frame) "
+                                          "/ this run's frame time"}
+    return roof
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c4r", "c5"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--band-rows", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-count", action="store_true", help="skip the untimed test-counting frame")
-    args = ap.parse_args()
+    ap.add_argument("--no-count", action="store_true", help="skip the untimed counting / serial-timing frames")
+    return ap.parse_args(argv)
+
+
+def launch_plan(gpus, env, argv):
+    """What this process must do about --gpus N, decided BEFORE anything touches the GPU.
+
+    ("run", None)      this process is the job (N == 1) or one rank of it (WORLD_SIZE == N, started by
+                       torch.distributed.run -- the driver's own command for N > 1)
+    ("spawn", cmd)     plain `python bench.py --gpus N` with N > 1: start N fresh rank processes with `cmd`
+                       (a subprocess, never an exec) and relay rank 0's JSON line
+    ("error", text)    WORLD_SIZE disagrees with --gpus: never print a line whose n_gpus is not the N asked for"""
+    if gpus < 1:
+        return "error", "--gpus must be >= 1"
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        if gpus == 1:
+            return "run", None
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        return "spawn", cmd
+    if int(ws) != gpus:
+        return "error", "bench.py --gpus %d was started with WORLD_SIZE=%s: the two must agree" % (gpus, ws)
+    return "run", None
+
+
+def main():
+    args = parse_args()
+    what, arg = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if what == "error":
+        raise SystemExit("bench.py: " + arg)
+    if what == "spawn":
+        # the parent makes no GPU call at all: it starts the ranks, relays their output and exits with their status
+        p = subprocess.run(arg, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+        raise SystemExit(p.returncode)
 
     import numpy as np
     import torch
@@ -121,6 +282,7 @@ def main():
         p = rt.Params.make(W, H, md, nranks=world, rank=rank, band_rows=args.band_rows if world > 1 else 0,
                            device=local_rank, flags=flags)
         return rt.Context(scene, p)
+    make_ctx.scene, make_ctx.device = scene, local_rank
 
     ctx = make_ctx(rt.host.F_TIME_KERNELS)
     nrows = len(ctx.rows)
@@ -172,8 +334,9 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5" if args.workload == "c4"
-                      else "Mrays/sec (primary+secondary+shadow rays traced) at 8K depth 8",
+            "metric": {"c4": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5",
+                       "c4r": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5, 5% refractive variant",
+                       "c5": "Mrays/sec (primary+secondary+shadow rays traced) at 8K depth 8"}[args.workload],
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -186,75 +349,9 @@ def main():
                                           "shadow": float(rays[2].item())}},
         }
 
-    # ---- roofline of the dominant kernel (rank 0's share of the frame) ----
+    # ---- roofline (rank 0, N = 1): EXECUTED work of the production kernels / their non-overlapped launch time ----
     if rank == 0:
-        kern = {"k_shadow_pass": (st.ms_shadow, st.launches_shadow),
-                "k_closest_lanes": (st.ms_closest_lanes, st.launches_closest_lanes),
-                "k_closest_f": (st.ms_closest, st.launches_closest)}
-        dom = max(kern, key=lambda k: kern[k][0])
-        ms_dom, n_dom = kern[dom]
-        roof = {"bound": "valu-fp32", "kernel": dom, "achieved": None,
-                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                "peak_no_fma": PEAK_FP32_NOFMA_TFLOPS, "frac_no_fma": None,
-                "launches_per_frame": n_dom, "avg_launch_ms": ms_dom / max(n_dom, 1),
-                "ms_per_frame_by_kernel": {k: v[0] for k, v in kern.items()}, "ms_frame": st.ms_total,
-                "note": "achieved = the REFERENCE algorithm's test FLOPs for the rays this kernel traces (every primitive in file "
-                        "order, shadow rays leaving at their first blocker; counted by the exact kernels in an untimed frame) / "
-                        "this kernel's summed launch time (HIP events on its own stream; launches of different streams overlap, "
-                        "so the per-kernel times add up to more than ms_frame).  The kernel reaches the same answers "
-                        "through a cluster hierarchy and executes a small part of those tests, hence frac > 1: see DESIGN.md 4.3 "
-                        "for the executed-instruction counters."}
-        if not args.no_count:
-            cctx = make_ctx(rt.host.F_COUNT_TESTS)
-            cctx.render(stream, None)
-            cst = cctx.stats()
-            if dom == "k_shadow_pass":
-                kinds = [float(x) for x in cst.tests_shadow_kind]
-            else:
-                # the counting kernel sums over generations; closest-hit tests every primitive for every ray, so a
-                # generation's share is its share of the rays
-                tot = float(st.rays_primary + st.rays_secondary)
-                share = float(st.rays_primary if dom == "k_closest_f" else st.rays_secondary) / max(tot, 1.0)
-                kinds = [float(x) * share for x in cst.tests_closest_kind]
-            flops = sum(float(kinds[k]) * FLOP_PER_TEST[k] for k in range(4))
-            ach = flops / (ms_dom * 1e-3) / 1e12
-            roof.update(achieved=ach, frac=ach / PEAK_FP32_TFLOPS, frac_no_fma=ach / PEAK_FP32_NOFMA_TFLOPS,
-                        flops_per_frame=flops, tests_per_frame=[float(k) for k in kinds])
-            cctx.close()
-        # HBM traffic of that kernel: not collectable inside this run (counter passes are separate rocprofv3 runs,
-        # tools/pmc_passes.sh); taken from the newest committed passes over the same frame, per launch
-        if args.workload == "c4" and not (args.width or args.height) and world == 1:
-            import csv, glob
-            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_c4.csv")))
-            for row in (csv.DictReader(open(files[-1])) if files else []):
-                if row["kernel"].replace("rtx::", "").split("<")[0] == dom and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
-                    launches = max(float(row["dispatches_per_pass"]), 1.0)
-                    fetch_kb, write_kb = float(row["FETCH_SIZE"]) / launches, float(row["WRITE_SIZE"]) / launches
-                    # the guide's gfx950 correction: FETCH_SIZE tallies wide (16 B / lane) reads at half their bytes; the
-                    # kernel mixes widths, so the doubled figure is an upper bound
-                    roof["traffic"] = (2.0 * fetch_kb + write_kb) * 1024.0
-                    roof["traffic_note"] = ("bytes per launch from %s (FETCH_SIZE x 2 + WRITE_SIZE, KB): an upper bound, against "
-                                            "%.3g algorithmic FLOPs per launch" % (os.path.basename(files[-1]), roof.get("flops_per_frame", 0.0) / max(n_dom, 1)))
-        # executed side, whole frame: wave-level VALU instructions (same counter passes) / the live frame time, against
-        # the issue rate the nominal FP32 peak implies (157.3 TFLOP/s = 2 FLOPs x 64 lanes x 1,229 G wave-instructions/s)
-        if args.workload == "c4" and not (args.width or args.height) and world == 1 and files:
-            tot, frames = 0.0, None
-            for row in csv.DictReader(open(files[-1])):
-                name = row["kernel"].replace("rtx::", "")
-                if name.startswith("k_affine_cells"):
-                    continue                      # context creation, not the frame
-                if name.startswith("k_raygen"):
-                    frames = float(row["dispatches_per_pass"])   # one launch per frame
-                tot += float(row.get("SQ_INSTS_VALU", 0.0) or 0.0)
-            if frames and tot:
-                per_frame = tot / frames
-                rate = per_frame / (st.ms_total * 1e-3) / 1e9
-                peak_issue = PEAK_FP32_TFLOPS * 1e12 / 128.0 / 1e9
-                roof["valu_issue"] = {"wave_instr_per_frame": per_frame, "G_instr_per_s": rate, "peak_G_instr_per_s": peak_issue,
-                                      "frac": rate / peak_issue, "source": os.path.basename(files[-1]),
-                                      "note": "SQ_INSTS_VALU summed over the frame's kernels (counter passes over the same frame, "
-                                              "committed) / this run's frame time; active lanes per instruction: DESIGN.md 4.5"}
-        out["roofline"] = roof
+        out["roofline"] = roofline(rt, make_ctx, stream, st, args, W, H, wl, world)
     # ---- end to end at the C-ABI: untimed extras, N = 1 only ----
     if rank == 0 and world == 1:
         import numpy as np

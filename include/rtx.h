@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 0x00020000u
+#define RTX_ABI_VERSION 0x00030000u
 
 /* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
  * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
@@ -117,12 +117,18 @@ typedef struct rtx_params {
 #define RTX_F_NO_HALO       8u  /* accounting only: trace the owned rows without the one-row halo and skip the
                                    antialias step (framebuffer undefined).  Gives a rank's UNIQUE ray counts. */
 #define RTX_F_PACKET_STATS 16u  /* fill rtx_stats.packet_stats (adds atomics to the intersection kernels: slower) */
+#define RTX_F_SERIAL       32u  /* enqueue every kernel of the frame on the caller's stream, in order: no side streams, no
+                                   fork / join events, one set of shadow-queue buffers.  Same image; kernel durations do
+                                   not overlap, which is what a per-kernel roofline needs (bench.py). */
+#define RTX_F_COUNT_EXEC   64u  /* run the counting instantiations of the PRODUCTION intersection kernels (slower: atomics):
+                                   what they actually evaluate, by kind -> rtx_stats.exec_counts.  Same image. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
                                    exact ray x primitive tests executed, by kind -> rtx_stats.tests_*_kind */
 
 /* Work actually done by the last render of a context (all counts are for this rank's rows,
  * halo rows included). */
 #define RTX_MAX_LEVELS 32
+#define RTX_EXEC_KINDS 16
 typedef struct rtx_stats {
     uint64_t rays_primary;      /* generation-0 rays traced */
     uint64_t rays_secondary;    /* reflection + refraction rays traced */
@@ -154,6 +160,15 @@ typedef struct rtx_stats {
     float    ms_closest_lanes;  /* RTX_F_TIME_KERNELS only: summed device time of the per-ray closest-hit launches of
                                    generations >= 1 (k_closest_lanes) */
     int32_t  launches_closest_lanes;
+    /* RTX_F_COUNT_EXEC only (0 otherwise): EXECUTED work of the production kernels, [kernel][kind].  kernel: 0 k_closest_f
+     * (generation 0), 1 k_closest_lanes (generations >= 1), 2 k_shadow_pass.  kind (one count per (ray or packet, sphere
+     * or primitive) pair a lane evaluated): 0 packet tests (a bounding sphere against a wave's packet), 1 cone tests (an
+     * enclosing sphere against one ray), 2 per-ray bounding-sphere filter tests, 3 the same for affine spheres on shadow
+     * rays, 4 affine strip tests, 5 exact sphere tests (raytracing.cpp:202-228), 6 exact affine-sphere tests, 7 exact
+     * triangle tests that left at vd == 0 or t < 0 (:340-350), 8 ... that left at the nearest-t cull (t >= nearest),
+     * 9 ... that ran the three areas (:352-365), 10 polygon fan triangles tested, 11 packets built, 12 rays traced,
+     * 13 exact triangle tests that left at the edge filter. */
+    uint64_t exec_counts[3][RTX_EXEC_KINDS];
 } rtx_stats;
 
 enum {
@@ -210,22 +225,25 @@ int  rtx_context_stats(rtx_context* ctx, rtx_stats* stats_out);
 int  rtx_band_rows(int32_t height, int32_t nranks, int32_t rank, int32_t band_rows,
                    int32_t* rows_out, int32_t capacity);
 
-/* ---- diagnostics (pure host function; no counterpart in the reference) ------------------------
- * The conservative bounding spheres the intersection kernels filter with, one { c.x, c.y, c.z,
- * -R^2 } record per primitive (spheres first, then triangles), and the origin guard beyond which
- * a ray bypasses the filter.  out4 holds 4 * (nspheres + ntriangles) floats.  Lets the CPU test
- * suite prove the filter never rejects a pair the reference's test accepts. */
-int  rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out);
+/* ---- diagnostics (pure host functions; no counterpart in the reference) -----------------------
+ * All three validate the scene view like rtx_context_create, return the number of records (or a negative
+ * RTX_E_* code), accept a NULL output pointer to query that number, and fail with RTX_E_INVALID_ARG when
+ * `capacity` (in records) is smaller.
+ *
+ * rtx_filter_records: the conservative bounding spheres the intersection kernels filter with, one { c.x, c.y,
+ * c.z, -R^2 } record per primitive -- spheres first, then triangles, then one always-pass record (-R^2 = -inf)
+ * per polygon: nspheres + ntriangles + npolygons records of 4 floats -- and the origin guard beyond which a ray
+ * bypasses the filter.  Lets the CPU test suite prove the filter never rejects a pair the reference's test accepts. */
+int  rtx_filter_records(const rtx_scene* scene, float* out4, int32_t capacity, float* guard_out);
 /* The shadow-ray filter records of the affine spheres (16 floats each: rows a,b,c of the inverse's
- * linear part, centre, -R^2, sphere index as int bits, 2 pad).  Returns the record count; out16
- * may be NULL to query it. */
+ * linear part, centre, -R^2, sphere index as int bits, R and ||A||_F rounded up). */
 int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t capacity);
 
 /* The triangles' edge-filter records (8 floats each: a1.xyz, m, a2.xyz, Q; rtx_bounds.cpp): between the plane
  * intersection and the area square roots of raytracing.cpp:338-365 the kernels reject a point P with
  * |P - v|_1 <= Q whose barycentric coordinate a1.(P - v), a2.(P - v) or 1 - both is below -m (-2m for the
  * third).  Q = -1: never rejected.  Exported so the CPU suite can check that bound against the reference's test. */
-int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8);
+int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capacity);
 
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),

@@ -439,18 +439,25 @@ unsigned char orc_quantise(float v)
     return (unsigned char)i;
 }
 
-int orc_render_f32(const rtx_scene* sc, int width, int height, int max_depth,
-                   int row0, int row1, float* out, orc_counts* cnt)
+int orc_render_f32_rect(const rtx_scene* sc, int width, int height, int max_depth,
+                        int row0, int row1, int col0, int col1, float* out, orc_counts* cnt)
 {
     if (!sc || !out || width <= 0 || height <= 0 || row0 < 0 || row1 > height || row0 > row1) return -1;
+    if (col0 < 0 || col1 > width || col0 > col1) return -1;
     cam c = make_cam(sc, width, height);
     for (int y = row0; y < row1; y++)
-        for (int x = 0; x < width; x++) {
+        for (int x = col0; x < col1; x++) {
             V p = sample(sc, &c, max_depth, x, y, cnt);
-            float* o = out + ((size_t)(y - row0) * width + x) * 3;
+            float* o = out + ((size_t)(y - row0) * (col1 - col0) + (x - col0)) * 3;
             o[0] = p.x; o[1] = p.y; o[2] = p.z;
         }
     return 0;
+}
+
+int orc_render_f32(const rtx_scene* sc, int width, int height, int max_depth,
+                   int row0, int row1, float* out, orc_counts* cnt)
+{
+    return orc_render_f32_rect(sc, width, height, max_depth, row0, row1, 0, width, out, cnt);
 }
 
 /* rt.cpp:738-783 on an existing 1-spp image + :792-794 */

@@ -43,6 +43,10 @@ unsigned char orc_quantise(float v);
 /* rt.cpp:801-833 (render2d): 1 sample per pixel, rows [row0,row1), out[(row1-row0)*width*3] */
 int orc_render_f32(const rtx_scene* sc, int width, int height, int max_depth,
                    int row0, int row1, float* out, orc_counts* cnt);
+/* the same for the pixel rectangle rows [row0,row1) x columns [col0,col1) of the width x height frame (crops of
+ * frames too large for one CPU core): out[(row1-row0)*(col1-col0)*3] */
+int orc_render_f32_rect(const rtx_scene* sc, int width, int height, int max_depth,
+                        int row0, int row1, int col0, int col1, float* out, orc_counts* cnt);
 /* rt.cpp:719-797 (render2Dantialiasing).  literal_9x != 0 re-traces every neighbour sample as
  * the reference does (:745-776); 0 traces each pixel centre once and filters (SURVEY.md F9,
  * byte-identical).  out[height*width*3]. */

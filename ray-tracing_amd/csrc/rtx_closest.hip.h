@@ -96,11 +96,12 @@ __device__ __forceinline__ int stage_tile(float4* tile, const float4* bounds, in
 struct HitAcc { float nearest; int best; int tflag; float txf; };  // txf: t of the last affine-sphere record (thin mode)
 
 // exact closest-hit update for primitive k (wave-uniform), raytracing.cpp:385-403 / :407-418
-__device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3 d, F3 nd, HitAcc& h)
+__device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3 d, F3 nd, HitAcc& h, Exec* ex = nullptr)
 {
     if (k < S.ns) {
         float4 hh = S.sph_hot[k];
         int xf = S.sph_xf[k];
+        ex_add(ex, xf ? EX_SPHX : EX_SPH);
         F3 to = o, td = nd;
         if (xf) {
             const rtx_xmatrix& im = S.sph_im[k];
@@ -115,12 +116,16 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
         TriRec T = load_tri(S.tri_hot, k - S.ns);
         const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
         float t, vd;
-        if (triangle_test_edge(o, d, T, e0, e1, t, vd, h.nearest)) {
+        int exitp = 0;
+        const bool hit = triangle_test_edge(o, d, T, e0, e1, t, vd, h.nearest, ex ? &exitp : nullptr);
+        if (ex) ex_tri(ex, exitp);
+        if (hit) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
     } else {
         const float4* p = S.phot + (size_t)k * 5;
         float t;
+        ex_add(ex, EX_POLY, (unsigned)__float_as_int(p[1].z));
         if (polygon_test(o, d, p[0], p[1], S.poly_verts, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
@@ -129,12 +134,13 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 
 
 // exact_closest for a wave-uniform primitive k whose hot record sits in lane u's registers
-__device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, const PrimRec& pr, int u, bool pass, F3 o, F3 d, F3 nd, HitAcc& h)
+__device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, const PrimRec& pr, int u, bool pass, F3 o, F3 d, F3 nd, HitAcc& h, Exec* ex = nullptr)
 {
     const float4 q0 = bcast4(pr.q0, u);
     if (k < S.ns) {
         const float4 q4 = bcast4(pr.q4, u);
         const bool xf = q4.x != 0.0f;
+        if (pass) ex_add(ex, xf ? EX_SPHX : EX_SPH);
         F3 to = o, td = nd;
         if (xf) {  // wave-uniform
             const float4 q1 = bcast4(pr.q1, u), q2 = bcast4(pr.q2, u), q3 = bcast4(pr.q3, u);
@@ -158,12 +164,16 @@ __device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, co
         T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
         T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
         float t, vd;
-        if (pass && triangle_test(o, d, T, t, vd)) {
+        int exitp = 0;
+        const bool hit = pass && triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr);
+        if (ex && pass) ex_tri(ex, exitp);
+        if (hit) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
     } else {
         const float4 q1 = bcast4(pr.q1, u);
         float t;
+        if (pass) ex_add(ex, EX_POLY, (unsigned)__float_as_int(q1.z));
         if (pass && polygon_test(o, d, q0, q1, S.poly_verts, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
@@ -292,7 +302,7 @@ __device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
 }
 
 template <bool PREFETCH>
-__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile)
+__device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, Exec* ex)
 {
     const int lane = threadIdx.x & 63;
     const int q = base + threadIdx.x;
@@ -314,6 +324,8 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     const F3 cam = f3(__shfl(o.x, src0), __shfl(o.y, src0), __shfl(o.z, src0));
     const bool one_origin = __all(!live || (o.x == cam.x && o.y == cam.y && o.z == cam.z));
     const Packet P = make_packet(o, nd, live, abn, one_origin, cam);
+    if (lane == 0) ex_add(ex, EX_WAVES);
+    if (live) ex_add(ex, EX_RAYS);
     int pk_batches = 0, pk_surv = 0;
     const int nprim = S.ns + S.nt + S.np;
     // this wave's bitmap of candidate primitives of the current segment (wave-private LDS: the wave's
@@ -330,6 +342,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
             for (int cb = c0; cb < c1; cb += 64) {
                 const int c = cb + lane;
                 unsigned long long cm = __ballot(c < c1 && packet_test(P, S.ccl[min(c, c1 - 1)]));
+                if (c < c1) ex_add(ex, EX_PACKET);
                 pk_batches++;
                 while (cm) {
                     if constexpr (PREFETCH) {
@@ -348,6 +361,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
 #pragma unroll
                         for (int a = 0; a < 4; a++) {
                             const bool pass = jj[a] >= 0 && kk[a] >= 0 && packet_test(P, mb[a]);
+                            if (jj[a] >= 0 && kk[a] >= 0) ex_add(ex, EX_PACKET);
                             if (pass) atomicOr(const_cast<unsigned*>(bm) + ((kk[a] - p0) >> 5), 1u << ((kk[a] - p0) & 31));
                             if (jj[a] >= 0) { pk_batches++; pk_surv += __popcll(__ballot(pass)); }
                         }
@@ -358,6 +372,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                         const float4 mb = S.cmem[m];
                         const int k = S.cidx[m];
                         const bool pass = k >= 0 && packet_test(P, mb);
+                        if (k >= 0) ex_add(ex, EX_PACKET);
                         if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
                         pk_batches++; pk_surv += __popcll(__ballot(pass));
                     }
@@ -409,7 +424,8 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                 for (int u = 0; u < m; u++) {
                     const float4 b = bcast4(br, u);
                     const bool pass = live && (abn || !(filt(fo, fd, b) < 0.0f));
-                    if (__any(pass)) exact_closest_bcast(S, __builtin_amdgcn_readlane(k, u), pr, u, pass, o, d, nd, h);
+                    if (use) ex_add(ex, EX_FILT);
+                    if (__any(pass)) exact_closest_bcast(S, __builtin_amdgcn_readlane(k, u), pr, u, pass, o, d, nd, h, ex);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -429,7 +445,8 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                     bits &= bits - 1;
                     const int k = p0 + ((w0 + j) << 5) + bpos;
                     const float4 br = S.bounds[k];
-                    if (live && (abn || !(filt(fo, fd, br) < 0.0f))) exact_closest(S, k, o, d, nd, h);
+                    if (use) ex_add(ex, EX_FILT);
+                    if (live && (abn || !(filt(fo, fd, br) < 0.0f))) exact_closest(S, k, o, d, nd, h, ex);
                 }
             }
         }
@@ -473,12 +490,13 @@ struct LexAcc {
 // exact test of primitive k (per lane): 0 miss | 1 plain sphere | 2 triangle or polygon | 3 affine sphere, t set on a hit.
 // The primitive's 80-byte hot record (SceneDev::phot) comes in with five independent loads: one memory
 // round trip, where sph_hot -> sph_xf -> sph_im was a chain of three.
-__device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F3 nd, float& t)
+__device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F3 nd, float& t, Exec* ex = nullptr)
 {
     const float4* p = S.phot + (size_t)k * 5;
     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
     if (k < S.ns) {
         const bool xf = q4.x != 0.0f;
+        ex_add(ex, xf ? EX_SPHX : EX_SPH);
         F3 to = o, td = nd;
         if (xf) {
             rtx_xmatrix im;
@@ -490,6 +508,7 @@ __device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F
         }
         return sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t) ? (xf ? 3 : 1) : 0;
     } else if (k >= S.ns + S.nt) {
+        ex_add(ex, EX_POLY, (unsigned)__float_as_int(q1.z));
         return polygon_test(o, d, q0, q1, S.poly_verts, t) ? 2 : 0;
     } else {
         TriRec T;
@@ -499,7 +518,10 @@ __device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F
         T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
         T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
         float vd;
-        return triangle_test(o, d, T, t, vd) ? 2 : 0;
+        int exitp = 0;
+        const bool hit = triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr);
+        if (ex) ex_tri(ex, exitp);
+        return hit ? 2 : 0;
     }
 }
 
@@ -579,7 +601,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 }
 
 template <int R>
-__device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W)
+__device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W, Exec* ex)
 {
     constexpr int kPer = 64 / R;                                  // lanes per ray in stage A
     constexpr int kPoolQ = (kPoolB / R < 32) ? kPoolB / R : 32;   // clusters per round
@@ -593,6 +615,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
     F3 nd = normalized(d);
     const bool abn = live && ray_abnormal(o, d, nd, S.guard);
+    if (live) ex_add(ex, EX_RAYS);
     if (lane < R) {
         W.rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
         W.rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
@@ -636,7 +659,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         const float4 rO = W.rayO[rr], rN = W.rayN[rr], rD = W.rayD[rr];
         float t = 0.0f;
         int kind = 0;
-        if (has) kind = exact_hit(S, k, f3(rO.x, rO.y, rO.z), f3(rD.x, rD.y, rD.z), f3(rN.x, rN.y, rN.z), t);
+        if (has) kind = exact_hit(S, k, f3(rO.x, rO.y, rO.z), f3(rD.x, rD.y, rD.z), f3(rN.x, rN.y, rN.z), t, ex);
         tested += cnt;
         nD = base;
         deliver(kind != 0, rr, k, t, kind);
@@ -660,8 +683,10 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         nC = base;
         unsigned pmask = 0u;
 #pragma unroll
-        for (int v = 0; v < kGroup; v++)
+        for (int v = 0; v < kGroup; v++) {
+            if (has && use && kk[v] >= 0) ex_add(ex, EX_FILT);
             if (kk[v] >= 0 && (!use || (front ? filt_front(fo, fd, mb[v]) : !(filt(fo, fd, mb[v]) < 0.0f)))) pmask |= 1u << v;
+        }
         if (!has) pmask = 0u;
         // pushes in MEMBER order: neighbouring lanes (rays of one group) that pass the same member sit together in D
 #pragma unroll
@@ -692,6 +717,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
 #pragma unroll
         for (int v = 0; v < 8; v++)
             if (rabn || !((front ? cone_slack_front(ro, rn, sb[v]) : cone_slack(ro, rn, sb[v])) < 0.0f)) gmask |= 1u << v;
+        if (has && !rabn) ex_add(ex, EX_CONE, 8u);
         if (!has) gmask = 0u;
         // pushes in GROUP order (the lanes are already in cluster order): the 64 entries of a C step then name
         // few distinct groups, whose members neighbouring lanes read together; a C step as soon as 64 entries wait
@@ -722,6 +748,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
             unsigned cmask = 0u;
             for (int u = part; u < ce; u += kPer) {
                 const float4 b = W.csph[u];
+                if (alive && !aabn) ex_add(ex, EX_CONE);
                 if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << u;
             }
             if (!alive) cmask = 0u;
@@ -756,7 +783,8 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         const int nprim = S.ns + S.nt + S.np;
         for (int k = 0; k < nprim; k++) {
             const float4 b = S.bounds[k];
-            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs);
+            if (slow && !abn) ex_add(ex, EX_FILT);
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs, ex);
         }
         if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
     }
@@ -793,7 +821,7 @@ __device__ __forceinline__ int stage_thin(float4* mt, const float4* bounds, int 
     return cnt;
 }
 
-__device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& L, const int n, float4* tile)
+__device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& L, const int n, float4* tile, Exec* ex)
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 64 + lane;  // the four waves hold the same 64 rays
@@ -804,6 +832,7 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     F3 nd = normalized(d);
     const bool abn = ray_abnormal(o, d, nd, S.guard);
     const bool use = live && !abn;
+    if (live && w == 0) ex_add(ex, EX_RAYS);
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
     F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
     unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
@@ -824,10 +853,11 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
             unsigned acc = accinit;
 #pragma unroll
             for (int u = 0; u < kGroup; u++) acc &= __float_as_uint(filt(fo, fd, mt[g + u]));
+            if (use) ex_add(ex, EX_FILT, (unsigned)min(kGroup, cnt - g));
             if ((int)acc >= 0) {
                 int gend = min(kGroup, cnt - g);
                 for (int u = 0; u < gend; u++)
-                    if (live && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h);
+                    if (live && (abn || !(filt(fo, fd, mt[g + u]) < 0.0f))) exact_closest(S, t0 + g + u, o, d, nd, h, ex);
             }
         }
     }
@@ -851,20 +881,24 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     }
 }
 
-template <bool PREFETCH>
+template <bool PREFETCH, bool EX = false>
 __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, const int* nrays)
 {
     __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps (2 KiB) and candidate lists (2 KiB)
     static_assert((kSegPrims / 32 + 512) * 4 * (kBlock / 64) <= kTile * 16, "bitmaps and lists fit");
     const int n = *nrays;
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
     if (n > kThinRays) {
         const int base = blockIdx.x * kBlock;
         if (base >= n) return;  // block-uniform
-        closest_packet<PREFETCH>(S, L, n, base, tile);
+        closest_packet<PREFETCH>(S, L, n, base, tile, ex);
     } else {
         if (blockIdx.x * 64 >= n) return;
-        closest_thin(S, L, n, tile);
+        closest_thin(S, L, n, tile, ex);
     }
+    ex_flush(ex, S.exec + 0 * EX_KINDS);
 }
 
 // Generations of at most kSplitClosest rays give a wave 16 rays instead of 64 (64 rays per workgroup): a thin
@@ -873,18 +907,23 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 constexpr int kSplitClosest = 1 << 17;
 constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
+template <bool EX = false>
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
 {
     __shared__ PoolLds pool[kBlock / 64];
     const int n = *nrays;
     const int w = threadIdx.x >> 6;
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
     if (n <= kSplitClosest) {
         if (blockIdx.x * 64 >= n) return;  // block-uniform
-        closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w]);
+        closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w], ex);
     } else {
         if (blockIdx.x * kBlock >= n) return;
-        closest_pool<64>(S, L, n, blockIdx.x * kBlock + w * 64, pool[w]);
+        closest_pool<64>(S, L, n, blockIdx.x * kBlock + w * 64, pool[w], ex);
     }
+    ex_flush(ex, S.exec + 1 * EX_KINDS);
 }
 
 

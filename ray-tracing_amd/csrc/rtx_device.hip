@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -113,13 +114,27 @@ struct rtx_context {
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
     hipStream_t last_stream = nullptr;
+    unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
     bool rendered = false;
     int nchunks = 0;
+    // Arena mode: every device buffer is carved out of a caller-provided block
+    // (the library's static scratch array) instead of hipMalloc; nothing is created or freed on the device.
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    bool serial = false;                    // RTX_F_SERIAL / arena mode: everything on the caller's stream, no side streams, no fork/join events
 
     template <typename T> int dalloc(T** p, size_t n)
     {
         void* q = nullptr;
         if (n == 0) n = 1;
+        if (arena) {
+            const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+            if (bytes > arena_cap - arena_off) return RTX_E_TOO_LARGE;
+            q = arena + arena_off;
+            arena_off += bytes;
+            *p = (T*)q;
+            return RTX_OK;
+        }
         HIPCHK(hipMalloc(&q, n * sizeof(T)));
         allocs.push_back(q);
         *p = (T*)q;
@@ -140,16 +155,7 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
     if (p->width <= 0 || p->height <= 0 || p->max_depth < 0) return RTX_E_INVALID_ARG;
     if (p->max_depth + 1 > RTX_MAX_LEVELS) return RTX_E_TOO_LARGE;
     if ((int64_t)p->width * p->height > (int64_t)1 << 30) return RTX_E_TOO_LARGE;
-    if (sc->nspheres < 0 || sc->ntriangles < 0 || sc->nlights < 0) return RTX_E_INVALID_ARG;
-    if ((sc->nspheres && !sc->spheres) || (sc->ntriangles && !sc->triangles) || (sc->nlights && !sc->lights))
-        return RTX_E_INVALID_ARG;
-    if (sc->npolygons < 0 || sc->npolygon_vertices < 0) return RTX_E_INVALID_ARG;
-    if ((sc->npolygons && !sc->polygons) || (sc->npolygon_vertices && !sc->polygon_vertices)) return RTX_E_INVALID_ARG;
-    for (int i = 0; i < sc->npolygons; i++) {
-        const rtx_polygon& g = sc->polygons[i];
-        if (g.numvertices < 0 || g.first_vertex < 0 || (int64_t)g.first_vertex + g.numvertices > (int64_t)sc->npolygon_vertices)
-            return RTX_E_INVALID_ARG;
-    }
+    if (int rc = validate_scene(sc)) return rc;
     if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
     if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= ((int64_t)1 << kPoolPrimBits)) return RTX_E_TOO_LARGE;  // closest_pool's list entries
     if (sc->nlights > 65535) return RTX_E_TOO_LARGE;  // gridDim.y
@@ -169,6 +175,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     HIPCHK(hipSetDevice(dev));
     c->device = dev;
     c->params = *params;
+    c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
     c->width = params->width;
     c->height = params->height;
     const int W = c->width, H = c->height;
@@ -298,8 +305,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             // (light, direction cell) -> affine spheres table for the shadow passes (k_affine_cells)
             const int words = (c->S.naff + 63) / 64;
             int G = 256;
-            while ((size_t)c->S.nl * G * G * words * 8 > ((size_t)256 << 20) && G > 16) G /= 2;
-            if ((size_t)c->S.nl * G * G * words * 8 <= ((size_t)256 << 20)) {
+            const size_t tab_limit = c->arena ? c->arena_cap / 8 : ((size_t)256 << 20);  // arena mode: the table may take an eighth of the block
+            while ((size_t)c->S.nl * G * G * words * 8 > tab_limit && G > 16) G /= 2;
+            if ((size_t)c->S.nl * G * G * words * 8 <= tab_limit) {
                 // the table covers origins up to the far corner of the scene box (rays from further away, possible
                 // only through the reference's odd hit points on affine spheres, make their wave test every sphere)
                 std::vector<float> dt(c->S.nl);
@@ -343,26 +351,57 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->dalloc(&c->d_rgb8, (size_t)nown * W * 3))) return rc;
     if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels))) return rc;
     // frame totals, test counters and packet statistics in one block: one memset per frame
-    if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels + 16))) return rc;
+    if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels + 16 + 3 * EX_KINDS))) return rc;
     c->d_tests = c->d_totals + 2 * levels;
     c->d_pstat = c->d_tests + 8;
     c->S.pstat = (params->flags & RTX_F_PACKET_STATS) ? c->d_pstat : nullptr;
+    c->S.exec = c->d_pstat + 8;  // written by the counting instantiations only (RTX_F_COUNT_EXEC)
 
-    if (levels >= 2) c->main_from = levels - 1;
-    // chunking: level k holds at most fanout^k rays per level-0 ray
-    const size_t slot_bytes = 24 + 4 + 4 + 12 + 4 + 24 + 8 + 4 + (size_t)c->S.nl;
-    double mult = 0, m = 1;
-    for (int k = 0; k < levels; k++) { mult += m; m *= (c->fanout >= 2 ? 2.0 : 1.0); }
+    if (c->serial) c->main_from = 0;  // every generation's shadow chain on the caller's stream, one set of queue buffers
+    else if (levels >= 2) c->main_from = levels - 1;
+    const int nside = c->serial ? 0 : std::min(levels, (int)rtx_context::kSide);
+    const int nlanes = nside + (c->main_from < levels ? 1 : 0);
+    const double fan = c->fanout >= 2 ? 2.0 : 1.0;
+    const size_t nl1 = (size_t)std::max(c->S.nl, 1);
+    c->binG = 256;
+    while (nl1 * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
+    c->nbins = (int)nl1 * c->binG * c->binG;
+    c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
+    // Device bytes of the ray queues for chunks of `rows` rows, allocation by allocation as below (arena mode
+    // rounds every allocation up to 256 bytes).  Level k holds at most fanout^k rays per level-0 ray.
+    auto plan = [&](int64_t rows) -> double {
+        auto al = [&](double b) { return c->arena ? std::ceil(b / 256.0) * 256.0 : b; };
+        double tot = 0, cap = (double)rows * W;
+        for (int k = 0; k < levels; k++) {
+            tot += 18.0 * al(cap * 4.0) + (k ? al(cap * 12.0) : 0.0) + al(cap * (double)nl1);
+            if (k + 1 < levels) cap *= fan;
+        }
+        const double qcap = cap * (double)nl1 + (double)c->qpad;
+        const double nb = (double)c->nbins, ng = std::ceil(nb / 1024.0);
+        tot += nlanes * (2.0 * al(qcap * 16.0) + 2.0 * al(nb * 4.0) + al(qcap * 4.0) + 2.0 * al(ng * 4.0));
+        const double nch = ntrace ? std::ceil((double)ntrace / (double)rows) : 1.0;
+        tot += al(nch * levels * 4.0);
+        return tot;
+    };
     uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
-    // per level-0 ray: every level's slots, plus the side streams' shadow-ray queues (28 B a ray + 4 B rank) sized for the largest level
-    double per_row = (double)W * (mult * (double)slot_bytes + (m / (c->fanout >= 2 ? 2.0 : 1.0)) * (double)(std::min(levels, (int)rtx_context::kSide) + (levels >= 2 ? 1 : 0)) * 32.0 * (double)c->S.nl);
-    int64_t rows = (int64_t)((double)budget / per_row);
-    if (rows < 1) rows = 1;
-    if (rows > ntrace) rows = ntrace;
-    // the deepest level's capacity must stay indexable by int
-    while (rows > 1 && (double)rows * W * (m / (c->fanout >= 2 ? 2.0 : 1.0)) * std::max(c->S.nl, 1) > (double)((int64_t)1 << 30)) rows /= 2;
-    c->chunk_rows = (int)std::max<int64_t>(rows, 1);
-    if (ntrace == 0) c->chunk_rows = 1;
+    if (c->arena) budget = c->arena_cap - c->arena_off;
+    int64_t rows = ntrace > 0 ? ntrace : 1;
+    // the deepest level's shadow queue must stay indexable by int
+    auto too_big = [&](int64_t r) { return (double)r * W * std::pow(fan, levels - 1) * (double)nl1 + (double)c->qpad > (double)(((int64_t)1 << 30)); };
+    if (plan(rows) > (double)budget || too_big(rows)) {
+        // bisect the largest chunk that fits (plan is monotone in rows)
+        int64_t lo = 0, hi = rows;  // lo fits (0 rows: nothing), hi does not
+        while (hi - lo > 1) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (plan(mid) > (double)budget || too_big(mid)) hi = mid; else lo = mid;
+        }
+        rows = lo;
+    }
+    if (rows < 1) {
+        if (c->arena || too_big(1)) return RTX_E_TOO_LARGE;  // not even one row of queues fits
+        rows = 1;  // a workspace_bytes cap below one row is a hint, not a limit
+    }
+    c->chunk_rows = (int)rows;
 
     c->L.resize(levels);
     size_t cap = (size_t)c->chunk_rows * W;
@@ -378,19 +417,13 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->dalloc(f, cap))) return rc;
         if (k == 0) L.val = nullptr;  // level-0 colours are written straight into the float image
         else if ((rc = c->dalloc(&L.val, cap * 3))) return rc;
-        if ((rc = c->dalloc(&L.lit, cap * (size_t)std::max(c->S.nl, 1)))) return rc;
-        if (c->fanout >= 2) cap *= 2;
+        if ((rc = c->dalloc(&L.lit, cap * nl1))) return rc;
+        if (c->fanout >= 2 && k + 1 < levels) cap *= 2;
     }
     {   // shadow-ray queues: the largest generation's hits x lights
-        size_t qcap = (size_t)c->L[levels - 1].cap * (size_t)std::max(c->S.nl, 1);
-        c->binG = 256;
-        while ((size_t)std::max(c->S.nl, 1) * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
-        c->nbins = std::max(c->S.nl, 1) * c->binG * c->binG;
-        c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
-        qcap += c->qpad;
+        size_t qcap = (size_t)c->L[levels - 1].cap * nl1 + c->qpad;
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
         const size_t maxbins = (size_t)c->nbins;
-        const int nside = std::min(levels, (int)rtx_context::kSide);
         for (int i = 0; i <= nside; i++) {
             if (i == nside && c->main_from >= levels) break;
             rtx_context::ShadowLane& sl = c->side[i == nside ? (int)rtx_context::kSide : i];
@@ -405,9 +438,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels))) return rc;
     }
+    if (c->arena) return RTX_OK;  // arena mode creates no streams and no events
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    for (int i = 0; i < std::min(levels, (int)rtx_context::kSide); i++) {
+    for (int i = 0; i < nside; i++) {
         HIPCHK(hipStreamCreateWithFlags(&c->side[i].stream, hipStreamNonBlocking));
     }
     c->ev_fork.resize(levels);
@@ -431,11 +465,12 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     HIPCHK(hipSetDevice(c->device));
     const int W = c->width, levels = c->levels;
     const int ntrace = (int)c->trace_rows.size(), nown = (int)c->own_rows.size();
-    HIPCHK(hipEventRecord(c->ev0, st));
-    HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * (2 * levels + 16), st));  // + d_tests, d_pstat
+    if (c->ev0) HIPCHK(hipEventRecord(c->ev0, st));
+    HIPCHK(hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * (2 * levels + 16 + 3 * EX_KINDS), st));  // + d_tests, d_pstat, exec
     // (d_scnt needs no clearing: k_scan_sums writes a generation's queue size before its pass reads it)
     const bool count = (c->params.flags & RTX_F_COUNT_TESTS) != 0;
     const bool exact_only = (c->params.flags & RTX_F_EXACT_ONLY) != 0;
+    const bool exec = (c->params.flags & RTX_F_COUNT_EXEC) != 0;
     const bool timek = !c->kev.empty();
     size_t kev_used = 0;
     c->kev_kind.clear();
@@ -462,10 +497,17 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) {
-                hipLaunchKernelGGL(k_closest_lanes, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+                const dim3 gl(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64)));
+                if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->S, Lk, rays + k);
+                else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->S, Lk, rays + k);
             }
-            else if (live_cap < kPrefetchRays) hipLaunchKernelGGL(k_closest_f<true>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
-            else hipLaunchKernelGGL(k_closest_f<false>, dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else if (live_cap < kPrefetchRays) {
+                if (exec) hipLaunchKernelGGL((k_closest_f<true, true>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+                else hipLaunchKernelGGL((k_closest_f<true, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            } else {
+                if (exec) hipLaunchKernelGGL((k_closest_f<false, true>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+                else hipLaunchKernelGGL((k_closest_f<false, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            }
             if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], st)); kev_used += 2; c->kev_kind.push_back((k > 0 && !count && !exact_only) ? 2 : 0); }
             // generation 0 runs alone and every workgroup allocates: 1024-thread workgroups quarter its same-address
             // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits
@@ -503,7 +545,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split4)) * kSplit));
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split8)) * 2 * kSplit));
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
-                hipLaunchKernelGGL(k_shadow_pass, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                if (exec) hipLaunchKernelGGL(k_shadow_pass<true>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                else hipLaunchKernelGGL(k_shadow_pass<false>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
                 if (!on_main) HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }
@@ -527,100 +570,16 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                                c->d_own_rows, nown, W, c->height, dst);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev1, st));
+    if (c->ev1) HIPCHK(hipEventRecord(c->ev1, st));
     c->last_stream = st;
+    c->last_dst = d_out ? d_out : c->d_rgb8;
     c->rendered = true;
     c->nchunks = nchunks;
     return RTX_OK;
 }
 
-extern "C" {
-
-int rtx_device_count(void)
+static int context_stats_impl(rtx_context* c, rtx_stats* s)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n < 0 ? 0 : n;
-}
-
-const char* rtx_last_hip_error(void) { return g_last_hip_error.c_str(); }
-
-int rtx_context_create(const rtx_scene* scene, const rtx_params* params, rtx_context** out)
-{
-    if (!out) return RTX_E_INVALID_ARG;
-    *out = nullptr;
-    int rc = validate(scene, params);
-    if (rc) return rc;
-    rtx_context* c = new (std::nothrow) rtx_context();
-    if (!c) return RTX_E_OOM;
-    rc = context_create_impl(scene, params, c);
-    if (rc) { rtx_context_destroy(c); return rc; }
-    *out = c;
-    return RTX_OK;
-}
-
-void rtx_context_destroy(rtx_context* c)
-{
-    if (!c) return;
-    if (!c->allocs.empty() || c->ev0 || c->ev1 || !c->kev.empty()) {
-        (void)hipSetDevice(c->device);
-        if (c->rendered) (void)hipStreamSynchronize(c->last_stream);
-        for (void* p : c->allocs) (void)hipFree(p);
-        if (c->ev0) (void)hipEventDestroy(c->ev0);
-        if (c->ev1) (void)hipEventDestroy(c->ev1);
-        for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
-        for (auto e : c->ev_fork) if (e) (void)hipEventDestroy(e);
-        for (auto e : c->ev_pass) if (e) (void)hipEventDestroy(e);
-        for (rtx_context::ShadowLane& sl : c->side) {
-            if (sl.stream) (void)hipStreamDestroy(sl.stream);
-        }
-    }
-    delete c;
-}
-
-int rtx_context_rows(const rtx_context* c, int32_t* rows_out, int32_t capacity)
-{
-    if (!c) return RTX_E_INVALID_ARG;
-    int n = (int)c->own_rows.size();
-    if (rows_out) {
-        if (capacity < n) return RTX_E_INVALID_ARG;
-        std::memcpy(rows_out, c->own_rows.data(), sizeof(int32_t) * n);
-    }
-    return n;
-}
-
-int rtx_context_render(rtx_context* c, void* hip_stream, uint8_t* d_rgb8_out)
-{
-    if (!c) return RTX_E_INVALID_ARG;
-    return context_render_impl(c, (hipStream_t)hip_stream, d_rgb8_out);
-}
-
-int rtx_context_read_rgb8(rtx_context* c, uint8_t* host)
-{
-    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->last_stream));
-    size_t n = c->own_rows.size() * (size_t)c->width * 3;
-    if (n) HIPCHK(hipMemcpy(host, c->d_rgb8, n, hipMemcpyDeviceToHost));
-    return RTX_OK;
-}
-
-int rtx_context_read_f32(rtx_context* c, float* host)
-{
-    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->last_stream));
-    size_t rowf = (size_t)c->width * 3;
-    for (size_t r = 0; r < c->own_rows.size(); r++) {
-        int ti = c->row2ti[c->own_rows[r]];
-        HIPCHK(hipMemcpy(host + r * rowf, c->d_fimg + (size_t)ti * rowf, rowf * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    return RTX_OK;
-}
-
-int rtx_context_stats(rtx_context* c, rtx_stats* s)
-{
-    if (!c || !s || !c->rendered) return RTX_E_INVALID_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     std::memset(s, 0, sizeof *s);
@@ -639,13 +598,20 @@ int rtx_context_stats(rtx_context* c, rtx_stats* s)
     s->chunks = c->nchunks;
     s->levels = c->levels;
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (c->ev0 && c->ev1) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));  // arena mode keeps no events: 0
     s->ms_total = ms;
     unsigned long long tk[8];
     HIPCHK(hipMemcpy(tk, c->d_pstat, sizeof tk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; k++) s->packet_stats[k] = tk[k];
     HIPCHK(hipMemcpy(tk, c->d_tests, sizeof tk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = tk[k]; s->tests_shadow_kind[k] = tk[4 + k]; }
+    {
+        static_assert(EX_KINDS <= RTX_EXEC_KINDS, "rtx_stats.exec_counts holds every kind");
+        unsigned long long ex[3 * EX_KINDS];
+        HIPCHK(hipMemcpy(ex, c->S.exec, sizeof ex, hipMemcpyDeviceToHost));
+        for (int kc = 0; kc < 3; kc++)
+            for (int k = 0; k < EX_KINDS; k++) s->exec_counts[kc][k] = ex[kc * EX_KINDS + k];
+    }
     for (size_t e = 0; e < c->kev_kind.size(); e++) {
         float m = 0;
         HIPCHK(hipEventElapsedTime(&m, c->kev[2 * e], c->kev[2 * e + 1]));
@@ -669,20 +635,8 @@ static int render_one(const rtx_scene* scene, const rtx_params* params, uint8_t*
     return rc;
 }
 
-int rtx_render_f32(const rtx_scene* scene, const rtx_params* params, float* out, rtx_stats* stats)
+static int render_multi(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
 {
-    if (!out) return RTX_E_INVALID_ARG;
-    int rc = validate(scene, params);
-    if (rc) return rc;
-    return render_one(scene, params, nullptr, out, stats);
-}
-
-int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
-{
-    if (!out) return RTX_E_INVALID_ARG;
-    int rc = validate(scene, params);
-    if (rc) return rc;
-    if (params->nranks > 1 || ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
     // In-process multi-GPU: one host thread per device, interleaved bands, each device copies
     // its own rows to the host over its own PCIe link; rows are placed in the caller's frame.
     int ndev = rtx_device_count();
@@ -723,6 +677,135 @@ int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
         }
     }
     return RTX_OK;
+}
+
+// No entry point lets a C++ exception cross the C-ABI (include/rtx.h): host-side allocations can throw.
+#define RTX_TRY try {
+#define RTX_CATCH                                                                             \
+    } catch (const std::bad_alloc&) { return RTX_E_OOM; }                                     \
+    catch (...) { g_last_hip_error = "unexpected C++ exception"; return RTX_E_HIP; }
+
+extern "C" {
+
+int rtx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+const char* rtx_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int rtx_context_create(const rtx_scene* scene, const rtx_params* params, rtx_context** out)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    *out = nullptr;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    rtx_context* c = nullptr;
+    RTX_TRY
+    c = new (std::nothrow) rtx_context();
+    if (!c) return RTX_E_OOM;
+    try { rc = context_create_impl(scene, params, c); }
+    catch (...) { rtx_context_destroy(c); throw; }
+    if (rc) { rtx_context_destroy(c); return rc; }
+    *out = c;
+    return RTX_OK;
+    RTX_CATCH
+}
+
+void rtx_context_destroy(rtx_context* c)
+{
+    if (!c) return;
+    if (c->rendered) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->last_stream);
+        for (rtx_context::ShadowLane& sl : c->side)
+            if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    }
+    if (!c->allocs.empty() || c->ev0 || c->ev1 || !c->kev.empty() || !c->ev_fork.empty()) {
+        (void)hipSetDevice(c->device);
+        for (void* p : c->allocs) (void)hipFree(p);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        for (auto e : c->kev) if (e) (void)hipEventDestroy(e);
+        for (auto e : c->ev_fork) if (e) (void)hipEventDestroy(e);
+        for (auto e : c->ev_pass) if (e) (void)hipEventDestroy(e);
+        for (rtx_context::ShadowLane& sl : c->side) {
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        }
+    }
+    delete c;
+}
+
+int rtx_context_rows(const rtx_context* c, int32_t* rows_out, int32_t capacity)
+{
+    if (!c) return RTX_E_INVALID_ARG;
+    int n = (int)c->own_rows.size();
+    if (rows_out) {
+        if (capacity < n) return RTX_E_INVALID_ARG;
+        std::memcpy(rows_out, c->own_rows.data(), sizeof(int32_t) * n);
+    }
+    return n;
+}
+
+int rtx_context_render(rtx_context* c, void* hip_stream, uint8_t* d_rgb8_out)
+{
+    if (!c) return RTX_E_INVALID_ARG;
+    RTX_TRY
+    return context_render_impl(c, (hipStream_t)hip_stream, d_rgb8_out);
+    RTX_CATCH
+}
+
+int rtx_context_read_rgb8(rtx_context* c, uint8_t* host)
+{
+    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    size_t n = c->own_rows.size() * (size_t)c->width * 3;
+    // the last frame's rows: in the context's own framebuffer, or in the device buffer the caller gave that render
+    if (n) HIPCHK(hipMemcpy(host, c->last_dst, n, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_context_read_f32(rtx_context* c, float* host)
+{
+    if (!c || !host || !c->rendered) return RTX_E_INVALID_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->last_stream));
+    size_t rowf = (size_t)c->width * 3;
+    for (size_t r = 0; r < c->own_rows.size(); r++) {
+        int ti = c->row2ti[c->own_rows[r]];
+        HIPCHK(hipMemcpy(host + r * rowf, c->d_fimg + (size_t)ti * rowf, rowf * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return RTX_OK;
+}
+
+int rtx_context_stats(rtx_context* c, rtx_stats* s)
+{
+    if (!c || !s || !c->rendered) return RTX_E_INVALID_ARG;
+    RTX_TRY
+    return context_stats_impl(c, s);
+    RTX_CATCH
+}
+
+int rtx_render_f32(const rtx_scene* scene, const rtx_params* params, float* out, rtx_stats* stats)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    return render_one(scene, params, nullptr, out, stats);
+}
+
+int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    if (params->nranks > 1 || ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
+    RTX_TRY
+    return render_multi(scene, params, ngpus, out, stats);
+    RTX_CATCH
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ struct SceneDev {
     int naff;
     F3 box_lo, box_inv;           // scene box for ray binning: cell = (o - box_lo) * box_inv, 16 cells per axis
     unsigned long long* pstat;    // [8] packet statistics: closest {waves, waves ok, batches, survivors}, shadow {same}
+    unsigned long long* exec;     // [3 * EX_KINDS] executed-work counters of k_closest_f / k_closest_lanes / k_shadow_pass (RTX_F_COUNT_EXEC)
     const float4* sbounds;        // [nsb] filter records of the shadow casters except affine spheres (transposed scan of
     const int* sorder;            // [nsb]  unpacketable rays), and the primitive index of each
     int nsb;
@@ -174,6 +175,41 @@ __device__ __forceinline__ void flush_counts(const unsigned int (&n)[4], unsigne
     for (int k = 0; k < 4; k++) {
         unsigned int v = n[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
+    }
+}
+
+// Executed-work counters (RTX_F_COUNT_EXEC): what the PRODUCTION kernels actually evaluate, lane by lane -- one
+// count per (ray or packet, sphere / primitive) pair a lane works on whose result is used.  Per-lane tallies in
+// registers, one wave reduction and one atomic per kind at the end of the kernel; the counting instantiations
+// are separate kernels (template flag), the timed ones carry a compile-time null pointer and none of this.
+enum {
+    EX_PACKET = 0,   // packet_test: one bounding sphere against a wave's packet (28 FLOP, bench.py EXEC_FLOPS)
+    EX_CONE,         // cone_slack / cone_slack_front: one enclosing sphere against one ray's cone (25)
+    EX_FILT,         // filt / filt_front: one primitive's bounding sphere against one ray's line (16)
+    EX_AFILT,        // filt_affine: affine sphere, shadow-ray form (39)
+    EX_STRIP,        // affine_strip_pass: one affine sphere against a wave's strip packet (150)
+    EX_SPH,          // exact sphere test, raytracing.cpp:202-228 (20)
+    EX_SPHX,         // exact affine-sphere test incl. the inverse transform(s) (65; shadow form 47)
+    EX_TRI_EARLY,    // exact triangle test leaving at vd == 0 or t < 0 (13)
+    EX_TRI_CULL,     // ... leaving at the nearest-t cull, t >= nearest (13)
+    EX_TRI_FULL,     // ... through the three areas (76; the edge filter's 16 in front of them are not credited)
+    EX_POLY,         // exact polygon test (counted as a full triangle test per vertex)
+    EX_WAVES,        // packets built (make_packet)
+    EX_RAYS,         // rays the kernel traced
+    EX_TRI_EDGE,     // exact triangle test leaving at the edge filter (13 + P, vec1 and the filter: 38)
+    EX_KINDS
+};
+struct Exec { unsigned n[EX_KINDS]; };
+__device__ __forceinline__ void ex_add(Exec* ex, int kind, unsigned v = 1u) { if (ex) ex->n[kind] += v; }
+__device__ __forceinline__ void ex_zero(Exec* ex) { if (ex) for (int k = 0; k < EX_KINDS; k++) ex->n[k] = 0u; }
+__device__ __forceinline__ void ex_tri(Exec* ex, int exitp) { ex_add(ex, exitp == 0 ? EX_TRI_EARLY : exitp == 1 ? EX_TRI_CULL : exitp == 3 ? EX_TRI_EDGE : EX_TRI_FULL); }
+__device__ __forceinline__ void ex_flush(Exec* ex, unsigned long long* dst)
+{
+    if (!ex) return;
+    for (int k = 0; k < EX_KINDS; k++) {
+        unsigned int v = ex->n[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
     }
 }

@@ -347,23 +347,53 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
 
 }  // namespace rtx
 
-extern "C" int rtx_filter_records(const rtx_scene* scene, float* out4, float* guard_out)
+namespace rtx {
+// Pointer / count / range checks on a caller's scene view, shared by every entry point that reads one.
+int validate_scene(const rtx_scene* sc)
 {
-    if (!scene || !out4) return RTX_E_INVALID_ARG;
-    if ((scene->nspheres && !scene->spheres) || (scene->ntriangles && !scene->triangles)) return RTX_E_INVALID_ARG;
+    if (!sc) return RTX_E_INVALID_ARG;
+    if (sc->nspheres < 0 || sc->ntriangles < 0 || sc->nlights < 0 || sc->nplanes < 0) return RTX_E_INVALID_ARG;
+    if ((sc->nspheres && !sc->spheres) || (sc->ntriangles && !sc->triangles) || (sc->nlights && !sc->lights))
+        return RTX_E_INVALID_ARG;
+    if (sc->npolygons < 0 || sc->npolygon_vertices < 0) return RTX_E_INVALID_ARG;
+    if ((sc->npolygons && !sc->polygons) || (sc->npolygon_vertices && !sc->polygon_vertices)) return RTX_E_INVALID_ARG;
+    for (int i = 0; i < sc->npolygons; i++) {
+        const rtx_polygon& g = sc->polygons[i];
+        if (g.numvertices < 0 || g.first_vertex < 0 || (int64_t)g.first_vertex + g.numvertices > (int64_t)sc->npolygon_vertices)
+            return RTX_E_INVALID_ARG;
+    }
+    return RTX_OK;
+}
+}  // namespace rtx
+
+#define RTX_PACK_TRY try {
+#define RTX_PACK_CATCH } catch (const std::bad_alloc&) { return RTX_E_OOM; } catch (...) { return RTX_E_INVALID_ARG; }
+
+extern "C" int rtx_filter_records(const rtx_scene* scene, float* out4, int32_t capacity, float* guard_out)
+{
+    int rc = rtx::validate_scene(scene);
+    if (rc) return rc;
+    RTX_PACK_TRY
     rtx::PackedScene P;
     rtx::pack_scene(*scene, 1, 1, P);
-    for (size_t i = 0; i < P.bounds.size(); i++) {
-        out4[4 * i + 0] = P.bounds[i].cx; out4[4 * i + 1] = P.bounds[i].cy;
-        out4[4 * i + 2] = P.bounds[i].cz; out4[4 * i + 3] = P.bounds[i].neg_r2;
+    const int n = (int)P.bounds.size();  // spheres, triangles, then one always-pass record per polygon
+    if (out4) {
+        if (capacity < n) return RTX_E_INVALID_ARG;
+        for (int i = 0; i < n; i++) {
+            out4[4 * i + 0] = P.bounds[i].cx; out4[4 * i + 1] = P.bounds[i].cy;
+            out4[4 * i + 2] = P.bounds[i].cz; out4[4 * i + 3] = P.bounds[i].neg_r2;
+        }
     }
     if (guard_out) *guard_out = P.guard;
-    return RTX_OK;
+    return n;
+    RTX_PACK_CATCH
 }
 
 extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t capacity)
 {
-    if (!scene || (scene->nspheres && !scene->spheres)) return RTX_E_INVALID_ARG;
+    int rc = rtx::validate_scene(scene);
+    if (rc) return rc;
+    RTX_PACK_TRY
     rtx::PackedScene P;
     rtx::pack_scene(*scene, 1, 1, P);
     int n = (int)P.aff_shadow.size();
@@ -373,15 +403,19 @@ extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, i
         if (n) std::memcpy(out16, P.aff_shadow.data(), (size_t)n * 64);
     }
     return n;
+    RTX_PACK_CATCH
 }
 
-extern "C" int rtx_triangle_edge_records(const rtx_scene* scene, float* out8)
+extern "C" int rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capacity)
 {
-    if (!scene || !out8 || (scene->ntriangles && !scene->triangles)) return RTX_E_INVALID_ARG;
+    int rc = rtx::validate_scene(scene);
+    if (rc) return rc;
+    if (!out8) return scene->ntriangles;
+    if (capacity < scene->ntriangles) return RTX_E_INVALID_ARG;
     static_assert(sizeof(rtx::TriEdge) == 32, "8 floats");
     for (int i = 0; i < scene->ntriangles; i++) {
         const rtx::TriEdge e = rtx::tri_edge_filter(scene->triangles[i]);
         std::memcpy(out8 + (size_t)8 * i, &e, sizeof(e));
     }
-    return RTX_OK;
+    return scene->ntriangles;
 }

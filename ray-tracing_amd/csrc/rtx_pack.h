@@ -114,6 +114,7 @@ struct PackedScene {
     int max_fanout = 0;                  // max children one hit can spawn: [refl>0] + [transp>0]
 };
 
+int validate_scene(const rtx_scene* sc);  // RTX_OK or RTX_E_INVALID_ARG: pointers, counts, polygon vertex ranges
 rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular);
 void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& out);
 

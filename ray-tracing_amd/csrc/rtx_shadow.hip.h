@@ -6,19 +6,24 @@
 namespace rtx {
 
 // exact any-hit for primitive k (wave-uniform), raytracing.cpp:569-589
-__device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld, F3 nld)
+__device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld, F3 nld, Exec* ex = nullptr)
 {
     if (k < S.ns) {
         float4 hh = S.sph_hot[k];
         F3 td = nld;
-        if (S.sph_xf[k]) td = normalized(inv_apply(ld, S.sph_im[k]));
+        const int xf = S.sph_xf[k];
+        ex_add(ex, xf ? EX_SPHX : EX_SPH);
+        if (xf) td = normalized(inv_apply(ld, S.sph_im[k]));
         float t;
         return sphere_test(o, td, hh.x, hh.y, hh.z, hh.w, t);
     }
     TriRec T = load_tri(S.tri_hot, k - S.ns);
     const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
     float t, vd;
-    return triangle_test_edge(o, ld, T, e0, e1, t, vd);
+    int exitp = 0;
+    const bool hit = triangle_test_edge(o, ld, T, e0, e1, t, vd, __builtin_inff(), ex ? &exitp : nullptr);
+    if (ex) ex_tri(ex, exitp);
+    return hit;
 }
 
 // Shadow rays (raytracing.cpp:560-589) are any-hit: which primitive blocks the light first does not
@@ -316,7 +321,7 @@ constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: e
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
                                                    unsigned char* lit, const int lit_cap, const int part, const int parts,
-                                                   unsigned short* alist)
+                                                   unsigned short* alist, Exec* ex)
 {
     const int c0 = 0, c1 = S.nsb;
     const int lane = threadIdx.x & 63;
@@ -333,6 +338,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
     F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
     bool done = !live;
+    if (live && part == 0) ex_add(ex, EX_RAYS);
     int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0, pk_aff = 0;
     auto bcast4 = [](float4 v, int u) {
         float4 r;
@@ -403,6 +409,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         F3 apex = f3(0.0f, 0.0f, 0.0f);
         if (one_light) apex = f3(S.lights[li0].point);
         const Packet P = make_packet(o, nld, sel, abn, one_light, apex);
+        if (lane == 0) ex_add(ex, EX_WAVES);
         if (!P.ok && size > 1) { size >>= 1; continue; }
         remaining &= ~blk;
         if (!P.ok) { fallback |= blk; continue; }
@@ -416,6 +423,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             for (int cb = 0; cb < S.sncl && !out; cb += 64) {
                 const int c = cb + lane;
                 unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+                if (c < S.sncl && (c % parts) == part) ex_add(ex, EX_PACKET);
                 pk_batches++;
                 while (cm && !out) {
                     const int j = __ffsll((long long)cm) - 1;
@@ -424,13 +432,15 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     const float4 mb = S.smem[m];
                     const int k = S.sidx[m];
                     unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
+                    if (k >= 0) ex_add(ex, EX_PACKET);
                     pk_batches++; pk_surv += __popcll(mm);
                     while (mm) {
                         const int u = __ffsll((long long)mm) - 1;
                         mm &= mm - 1;
                         const float4 br = bcast4(mb, u);
+                        if (!done) ex_add(ex, EX_FILT);
                         if (!done && filt_front(fo, fd, br)) {
-                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld)) {
+                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld, ex)) {
                                 done = true;
                                 fo = f3(1e18f, 0.0f, 0.0f);
                                 fd = f3(0.0f, 0.0f, 0.0f);
@@ -470,6 +480,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
                     const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
                     bool pass = a0 + lane < nlist;
+                    if (pass) ex_add(ex, EX_STRIP);
                     if (pass) pass = affine_strip_pass(K, m0, m1, m2, m3);
                     unsigned long long am = __ballot(pass);
                     pk_batches++; pk_aff += __popcll(am);
@@ -477,8 +488,9 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         const int u = __ffsll((long long)am) - 1;
                         am &= am - 1;
                         const float4 b0 = bcast4(m0, u), b1 = bcast4(m1, u), b2 = bcast4(m2, u), b3 = bcast4(m3, u);
+                        if (!done) ex_add(ex, EX_AFILT);
                         if (!done && !(filt_affine(o, ld, b0, b1, b2, b3) < 0.0f)) {
-                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld)) {
+                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld, ex)) {
                                 done = true;
                                 fo = f3(1e18f, 0.0f, 0.0f);
                                 fd = f3(0.0f, 0.0f, 0.0f);
@@ -507,7 +519,8 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             bool hit = false;
             if (gi < c1) {
                 const float4 rec = S.sbounds[gi];
-                if (rabn || !(filt(rfo, rfd, rec) < 0.0f)) hit = exact_any(S, S.sorder[gi], ro, rl, rn);
+                if (!rabn) ex_add(ex, EX_FILT);
+                if (rabn || !(filt(rfo, rfd, rec) < 0.0f)) hit = exact_any(S, S.sorder[gi], ro, rl, rn, ex);
             }
             blocked = __any(hit);
         }
@@ -517,7 +530,8 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             if (ai < S.naff) {
                 const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
                 const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
-                if (rabn || !(filt_affine(ro, rl, m0, m1, m2, m3) < 0.0f)) hit = exact_any(S, __float_as_int(m3.y), ro, rl, rn);
+                if (!rabn) ex_add(ex, EX_AFILT);
+                if (rabn || !(filt_affine(ro, rl, m0, m1, m2, m3) < 0.0f)) hit = exact_any(S, __float_as_int(m3.y), ro, rl, rn, ex);
             }
             blocked = __any(hit);
         }
@@ -538,6 +552,7 @@ constexpr int kSplit = 4;
 constexpr int kSplitRays = 1 << 20;   // (re-measured after the edge filter: 2^21 / 2^19 cost 2 ranks 7 %, 8 ranks 4 % of their frame)
 constexpr int kSplitRays8 = 1 << 17;  // ... and by 2 * kSplit workgroups below this
 
+template <bool EX = false>
 __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
@@ -545,7 +560,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
     __shared__ unsigned short alist[kBlock / 64][kAffListCap];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
-    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6]);
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6], ex);
+    ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 
 

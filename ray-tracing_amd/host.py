@@ -13,6 +13,11 @@ F_COUNT_TESTS = 2
 F_EXACT_ONLY = 4
 F_NO_HALO = 8
 F_PACKET_STATS = 16
+F_SERIAL = 32
+F_COUNT_EXEC = 64
+RTX_EXEC_KINDS = 16
+EXEC_KERNELS = ("k_closest_f", "k_closest_lanes", "k_shadow_pass")
+EXEC_KINDS = ("packet", "cone", "filt", "afilt", "strip", "sph", "sphx", "tri_early", "tri_cull", "tri_full", "poly", "packets_built", "rays", "tri_edge")
 
 
 class RtxError(RuntimeError):
@@ -91,7 +96,12 @@ class Stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_closest", C.c_float), ("ms_shadow", C.c_float),
                 ("packet_stats", C.c_uint64 * 8),
                 ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32),
-                ("ms_closest_lanes", C.c_float), ("launches_closest_lanes", C.c_int32)]
+                ("ms_closest_lanes", C.c_float), ("launches_closest_lanes", C.c_int32),
+                ("exec_counts", (C.c_uint64 * RTX_EXEC_KINDS) * 3)]
+
+    def exec_dict(self):
+        """{kernel: {kind: count}} of the RTX_F_COUNT_EXEC counters."""
+        return {kn: {kd: int(self.exec_counts[i][j]) for j, kd in enumerate(EXEC_KINDS)} for i, kn in enumerate(EXEC_KERNELS)}
 
     @property
     def rays_total(self):
@@ -117,9 +127,9 @@ SYMBOLS = {
     "rtx_context_read_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtx_context_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtx_band_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
-    "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.POINTER(C.c_float)]),
+    "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
-    "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p]),
+    "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
     "rtx_write_ppm": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -220,16 +230,17 @@ def render_f32(scene, params):
 
 def filter_records(scene):
     """(records[nprims,4], guard): the kernels' conservative bounding spheres (rtx_filter_records)."""
-    out = np.zeros((scene.nprims, 4), dtype=np.float32)
+    n = _check(lib().rtx_filter_records(scene.ptr, None, 0, None), "rtx_filter_records")
+    out = np.zeros((n, 4), dtype=np.float32)
     g = C.c_float()
-    _check(lib().rtx_filter_records(scene.ptr, out.ctypes.data, C.byref(g)), "rtx_filter_records")
+    _check(lib().rtx_filter_records(scene.ptr, out.ctypes.data, n, C.byref(g)), "rtx_filter_records")
     return out, g.value
 
 
 def triangle_edge_records(scene):
     """records[ntriangles,8] float32: a1.xyz, m, a2.xyz, Q (rtx_triangle_edge_records)."""
     out = np.zeros((scene.view.ntriangles, 8), dtype=np.float32)
-    _check(lib().rtx_triangle_edge_records(scene.ptr, out.ctypes.data), "rtx_triangle_edge_records")
+    _check(lib().rtx_triangle_edge_records(scene.ptr, out.ctypes.data, scene.view.ntriangles), "rtx_triangle_edge_records")
     return out
 
 

@@ -152,6 +152,9 @@ def write_c5(path, ntriangles=100000, seed=SEED):
 WORKLOADS = {
     "c4": dict(width=3840, height=2160, max_depth=4, writer=write_c4,
                name="synthetic 4K, 5000 spheres (10% affine) + 5000 triangles, 4 lights, depth 5"),
+    # SURVEY.md 8d's second run: the same scene with 5 % of the primitives refractive (both kinds of secondary ray)
+    "c4r": dict(width=3840, height=2160, max_depth=4, writer=lambda path: write_c4(path, frac_refractive=0.05),
+                name="synthetic 4K, 5000 spheres (10% affine) + 5000 triangles, 5% refractive, 4 lights, depth 5"),
     "c5": dict(width=7680, height=4320, max_depth=7, writer=write_c5,
                name="synthetic 8K, 100000 triangles, 16 lights, depth 8"),
 }

@@ -63,7 +63,34 @@ def main():
         full = b"P6\n640 480 255\n" + ppm.tobytes()
         index["runs"].append(dict(scene=rel, width=640, height=480, max_depth=4, ppm=None, raw=None,
                                   ppm_md5=md5(full), trace=counts.get("trace"), shadow=counts.get("shadow")))
+        if rel == "bundled/inpaffine.txt":
+            # BASELINE.json configs[2]: the affine scene at 1920x1080 (md5 only)
+            ppm, counts = O.run_ref(path, 1920, 1080, 4)
+            index["runs"].append(dict(scene=rel, width=1920, height=1080, max_depth=4, ppm=None, raw=None,
+                                      ppm_md5=md5(b"P6\n1920 1080 255\n" + ppm.tobytes()), trace=counts.get("trace"), shadow=counts.get("shadow")))
         print(rel, "done")
+    # BASELINE.json configs[3] and [4]: the benchmark scenes themselves (ray-tracing_amd/scenegen.py, unmodified:
+    # 5,000 + 5,000 primitives / 100,000 triangles) on frames one CPU core finishes in minutes.  The scene files are
+    # too big to commit (2 / 20 MB); they are regenerated from the seeded generator and pinned by their md5.
+    import tempfile
+    import rtxamd as rt
+    for wl, (w, h) in (("c4", (48, 27)), ("c5", (24, 13))):
+        W = rt.scenegen.WORKLOADS[wl]
+        path = os.path.join(tempfile.gettempdir(), "golden_%s.txt" % wl)
+        W["writer"](path)
+        d = W["max_depth"]
+        ppm, counts = O.run_ref(path, w, h, d)
+        raw, _ = O.run_ref(path, w, h, d, raw=True)
+        stem = "%s_%dx%d_d%d" % (wl, w, h, d)
+        with open(os.path.join(HERE, stem + ".ppm"), "wb") as f:
+            f.write(b"P6\n%d %d 255\n" % (w, h))
+            f.write(ppm.tobytes())
+        raw.tofile(os.path.join(HERE, stem + ".f32"))
+        index["runs"].append(dict(scene="scenegen:" + wl, scene_md5=md5(open(path, "rb").read()), width=w, height=h, max_depth=d,
+                                  ppm=stem + ".ppm", raw=stem + ".f32", ppm_md5=md5(open(os.path.join(HERE, stem + ".ppm"), "rb").read()),
+                                  raw_md5=md5(raw.tobytes()), trace=counts.get("trace"), shadow=counts.get("shadow")))
+        os.remove(path)
+        print(wl, "done")
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1)
 

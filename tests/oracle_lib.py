@@ -30,6 +30,8 @@ def lib():
         SV = C.POINTER(rt.host.SceneView)
         L.orc_render_f32.restype = C.c_int
         L.orc_render_f32.argtypes = [SV, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Counts)]
+        L.orc_render_f32_rect.restype = C.c_int
+        L.orc_render_f32_rect.argtypes = [SV, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Counts)]
         L.orc_render_rgb8.restype = C.c_int
         L.orc_render_rgb8.argtypes = [SV, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Counts)]
         L.orc_filter_quantise.restype = None
@@ -50,11 +52,12 @@ def lib():
     return _lib
 
 
-def render_f32(scene, width, height, max_depth=4, row0=0, row1=None):
+def render_f32(scene, width, height, max_depth=4, row0=0, row1=None, col0=0, col1=None):
     row1 = height if row1 is None else row1
-    out = np.zeros((row1 - row0, width, 3), dtype=np.float32)
+    col1 = width if col1 is None else col1
+    out = np.zeros((row1 - row0, col1 - col0, 3), dtype=np.float32)
     cnt = Counts()
-    rc = lib().orc_render_f32(scene.ptr, width, height, max_depth, row0, row1, out.ctypes.data, C.byref(cnt))
+    rc = lib().orc_render_f32_rect(scene.ptr, width, height, max_depth, row0, row1, col0, col1, out.ctypes.data, C.byref(cnt))
     assert rc == 0
     return out, cnt
 

@@ -65,39 +65,81 @@ def test_context_reuse_and_device_output(rt, gpu):
     ctx.close()
 
 
+def test_render_into_a_device_buffer(rt, gpu):
+    """rtx_context_render with a caller's DEVICE output pointer (what bench.py and the RCCL gather use): the bytes
+    in that buffer, and what rtx_context_read_rgb8 returns afterwards, are the plain render's; RTX_F_SERIAL (one
+    stream, no side streams) gives the same frame."""
+    import ctypes as C
+    sc = rt.load_scene(os.path.join(SCENES, "probe.txt"))
+    W, H = 200, 120
+    want, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), W * H * 3) == 0
+    try:
+        for flags in (0, rt.host.F_SERIAL):
+            ctx = rt.Context(sc, rt.Params.make(W, H, 4, flags=flags))
+            ctx.render(None, buf)
+            got = ctx.read_rgb8()             # waits for the frame; copies from the caller's buffer
+            mine = np.zeros((H, W, 3), dtype=np.uint8)
+            assert hip.hipMemcpy(mine.ctypes.data, buf, W * H * 3, 2) == 0  # hipMemcpyDeviceToHost
+            assert np.array_equal(got, want) and np.array_equal(mine, want)
+            ctx.render()                      # back to the context's own framebuffer
+            assert np.array_equal(ctx.read_rgb8(), want)
+            ctx.close()
+    finally:
+        hip.hipFree(buf)
+
+
 def test_cli_is_a_drop_in(rt, oracle, gpu, tmp_path):
     """`raytrace_amd <scene> <out.ppm>` (raytracing.cpp:981-995): same arguments, same bytes as the
-    reference's 640x480 output (md5 fixtures of the real reference) on the bundled scenes."""
+    reference's 640x480 output (md5 fixtures of the real reference) on ALL FIVE bundled scenes
+    (BASELINE.json configs[0-2]); inpaffine.txt also at 1920x1080 (configs[2])."""
     import hashlib
     import json
     exe = os.path.join(ROOT, "ray-tracing_amd", "raytrace_amd")
     idx = json.load(open(os.path.join(GOLDEN, "index.json")))
-    want = {r["scene"]: r["ppm_md5"] for r in idx["runs"] if r["width"] == 640}
-    for name in ("inpaffine.txt", "inp.txt", "inp-refl.txt"):
+    want = {(r["scene"], r["width"]): r["ppm_md5"] for r in idx["runs"] if not r["ppm"]}
+    for name in ("inpaffine.txt", "inp.txt", "inp-refl.txt", "inp1.txt", "inp01.txt"):
         out = tmp_path / (name + ".ppm")
         subprocess.run([exe, os.path.join(GOLDEN, "bundled", name), str(out)], check=True, stdout=subprocess.DEVNULL)
-        assert hashlib.md5(out.read_bytes()).hexdigest() == want["bundled/" + name]
+        assert hashlib.md5(out.read_bytes()).hexdigest() == want[("bundled/" + name, 640)], name
+    out = tmp_path / "inpaffine_1080.ppm"
+    subprocess.run([exe, "--width=1920", "--height=1080", os.path.join(GOLDEN, "bundled", "inpaffine.txt"), str(out)],
+                   check=True, stdout=subprocess.DEVNULL)
+    data = out.read_bytes()
+    assert hashlib.md5(data).hexdigest() == want[("bundled/inpaffine.txt", 1920)]
+    # ... and against the oracle, pixel by pixel, at that size (one sphere: seconds on one core)
+    sc = rt.load_scene(os.path.join(GOLDEN, "bundled", "inpaffine.txt"))
+    rgb_cpu, _ = oracle.render_rgb8(sc, 1920, 1080, 4)
+    assert data[:17] == b"P6\n1920 1080 255\n"
+    assert np.array_equal(np.frombuffer(data[17:], dtype=np.uint8).reshape(1080, 1920, 3), rgb_cpu)
     # wrong argument count: usage text, exit status 0 (rt.cpp:983-988)
     p = subprocess.run([exe, "only-one-arg"], capture_output=True)
     assert p.returncode == 0 and b"Please follow the specifications!" in p.stdout
 
 
-def test_full_size_tierb_md5(rt, gpu):
-    """640x480 frames of the HEAD-grammar scenes against the md5 of the real reference's PPM.
-    (A frame may legitimately differ by the powf last-ulp cases; then fall back to the tolerance.)"""
+def test_full_size_tierb_md5(rt, oracle, gpu):
+    """640x480 frames of the HEAD-grammar scenes against the md5 of the real reference's PPM.  A frame whose md5
+    differs (a powf last-ulp case that reaches a byte) is not excused: it is compared with the oracle's 640x480
+    render under the north-star rule, every channel within 1 LSB and >= 99.9 % of pixels identical."""
     import hashlib
     import json
     idx = json.load(open(os.path.join(GOLDEN, "index.json")))
-    exact = 0
     runs = [r for r in idx["runs"] if r["width"] == 640 and r["scene"].startswith("scenes/")]
+    assert len(runs) >= 6
     for r in runs:
         sc = rt.load_scene(os.path.join(ROOT, "tests", r["scene"]))
         rgb, st = rt.render_rgb8(sc, rt.Params.make(640, 480, 4))
         md5 = hashlib.md5(b"P6\n640 480 255\n" + rgb.tobytes()).hexdigest()
-        exact += md5 == r["ppm_md5"]
-        # the reference's own ray counters: it re-traces 9x for antialiasing, we trace once
         print(r["scene"], "md5 identical:", md5 == r["ppm_md5"], "rays", st.rays_total)
-    assert exact >= len(runs) - 1
+        if md5 != r["ppm_md5"]:
+            rgb_cpu, _ = oracle.render_rgb8(sc, 640, 480, 4)
+            assert hashlib.md5(b"P6\n640 480 255\n" + rgb_cpu.tobytes()).hexdigest() == r["ppm_md5"]
+            print("   ", assert_rgb8_parity(rgb, rgb_cpu, r["scene"]))
 
 
 def test_c5_like_triangles_only(rt, oracle, gpu, tmp_path):
@@ -113,6 +155,70 @@ def test_c5_like_triangles_only(rt, oracle, gpu, tmp_path):
     rg, _ = rt.render_rgb8(sc, rt.Params.make(W, H, D))
     rc, _ = oracle.render_rgb8(sc, W, H, D)
     assert_rgb8_parity(rg, rc, "c5-like")
+
+
+@pytest.fixture(scope="module")
+def c5_scene(rt, tmp_path_factory):
+    """BASELINE.json configs[4], unmodified: scenegen.write_c5() = 100,000 triangles, 16 lights (7 closest-hit
+    segments, 1,563 shadow clusters)."""
+    p = tmp_path_factory.mktemp("c5") / "c5.txt"
+    rt.scenegen.write_c5(str(p))
+    sc = rt.load_scene(str(p))
+    assert (sc.view.ntriangles, sc.view.nlights) == (100000, 16)
+    return sc
+
+
+def test_c5_full_scene_matches_the_reference_fixture(rt, gpu, c5_scene):
+    """The real reference's output on the unmodified C5 scene at depth 8 (MAX_depth 7), 24x13 (tests/golden/
+    c5_24x13_d7.*, made by make_golden.py from oracle/_ref/rt_ref): float image and PPM."""
+    import json
+    run = [r for r in json.load(open(os.path.join(GOLDEN, "index.json")))["runs"] if r["scene"] == "scenegen:c5"][0]
+    W, H, D = run["width"], run["height"], run["max_depth"]
+    raw_ref = np.fromfile(os.path.join(GOLDEN, run["raw"]), dtype=np.float32).reshape(H, W, 3)
+    g, st = rt.render_f32(c5_scene, rt.Params.make(W, H, D))
+    assert st.levels == 8
+    same = raw_equal_mask(g, raw_ref)
+    assert same.mean() >= 0.999, int((~same).sum())
+    rgb, _ = rt.render_rgb8(c5_scene, rt.Params.make(W, H, D))
+    data = open(os.path.join(GOLDEN, run["ppm"]), "rb").read()
+    ppm = np.frombuffer(data[data.index(b"255\n") + 4:], dtype=np.uint8).reshape(H, W, 3)
+    assert_rgb8_parity(rgb, ppm, "c5 24x13")
+
+
+def test_c5_full_scene_crop_matches_oracle_at_8k(rt, oracle, gpu, c5_scene):
+    """The C5 frame's own geometry (7680x4320, depth 8): row 2000, columns 3600..3856, against the oracle (256 pixels
+    x ~15 rays x 100,000 tests: about half a minute of one core)."""
+    W, H, D = 7680, 4320, 7
+    row, c0, c1 = 2000, 3600, 3856
+    raw_cpu, cnt = oracle.render_f32(c5_scene, W, H, D, row, row + 1, c0, c1)
+    p = rt.Params.make(W, H, D, nranks=H, rank=row, band_rows=1)   # the band that is exactly that row
+    raw_gpu, st = rt.render_f32(c5_scene, p)
+    assert raw_gpu.shape == (1, W, 3)
+    same = raw_equal_mask(raw_gpu[:, c0:c1], raw_cpu)
+    print("c5 crop: %d of %d pixels bit-identical" % (int(same.sum()), same.size))
+    assert same.mean() >= 0.999
+
+
+def test_c5_full_scene_culled_equals_exact(rt, gpu, c5_scene):
+    """100,000 triangles, 16 lights, 8 generations: every culling stage (7 segments of the closest-hit hierarchy,
+    pooled traversal, 16 lights' direction maps, 1,563 shadow clusters, side streams) against the exact-only kernels
+    that walk all 100,000 triangles in file order, bit for bit -- on a reduced frame (480x270) and on one band of
+    the 7680x4320 frame's own geometry (8 rows = 61,440 pixels, row chunks forced by a small workspace)."""
+    W, H, D = 480, 270, 7
+    a, sa = rt.render_f32(c5_scene, rt.Params.make(W, H, D))
+    b, sb = rt.render_f32(c5_scene, rt.Params.make(W, H, D, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert sa.levels == 8 and sa.rays_level[7] > 0
+    W, H = 7680, 4320
+    pa = rt.Params.make(W, H, D, nranks=H // 8, rank=250, band_rows=8, workspace_bytes=64 << 20)
+    pb = rt.Params.make(W, H, D, nranks=H // 8, rank=250, band_rows=8, flags=rt.host.F_EXACT_ONLY)
+    a, sa = rt.render_rgb8(c5_scene, pa)
+    b, sb = rt.render_rgb8(c5_scene, pb)
+    assert sa.chunks >= 3 and sb.chunks == 1
+    assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert np.array_equal(a, b), "%d bytes differ" % int((a != b).sum())
 
 
 def test_no_halo_counts_sum_to_the_frame(rt, gpu):

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from conftest import GOLDEN, SCENES
+from conftest import GOLDEN, ROOT, SCENES
 
 
 def test_bundled_scenes_parse_as_the_head_grammar_does(rt):
@@ -89,3 +89,25 @@ def test_band_rows_partition(rt):
             assert all((y // bw) % n == r for y in rows)
         assert np.all(seen == 1)
     assert len(rt.band_rows(10, 1, 0, 0)) == 10
+
+
+def test_bench_launcher_honours_gpus():
+    """bench.py --gpus N (the driver's command): N > 1 without WORLD_SIZE spawns N ranks under
+    torch.distributed.run on 127.0.0.1 with the same arguments; a WORLD_SIZE that disagrees is an error;
+    the ranks themselves (WORLD_SIZE == N) and N == 1 just run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_plan(1, {}, []) == ("run", None)
+    assert bench.launch_plan(4, {"WORLD_SIZE": "4"}, []) == ("run", None)
+    what, cmd = bench.launch_plan(8, {}, ["--gpus", "8", "--steps", "3"])
+    assert what == "spawn"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert bench.launch_plan(8, {"WORLD_SIZE": "2"}, [])[0] == "error"
+    assert bench.launch_plan(1, {"WORLD_SIZE": "2"}, [])[0] == "error"
+    assert bench.launch_plan(0, {}, [])[0] == "error"
+    a = bench.parse_args(["--gpus", "2", "--workload", "c5"])
+    assert a.gpus == 2 and a.workload == "c5" and a.steps == 5
