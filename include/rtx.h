@@ -197,6 +197,19 @@ const char* rtx_last_hip_error(void);
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
                     uint8_t* rgb_out, rtx_stats* stats_or_null);
 
+/* The same call (ngpus = 1) for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference.  Scene records, ray queues, the
+ * float image and the 8-bit rows all live in one file-scope `static __device__` array of RTX_NOALLOC_SCRATCH_MIB MiB
+ * that every GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree, creates no
+ * stream and no event, and traces the frame in as many row chunks as that block needs (everything on the default
+ * stream, as RTX_F_SERIAL).  Same bytes and the same ray counts as rtx_render_rgb8; rtx_stats.ms_* stay 0.
+ * RTX_E_TOO_LARGE (text in rtx_last_hip_error) when the scene's device records, the (rows + halo) x width float image
+ * and one row of ray queues do not fit the block.  Every call on a GPU shares that GPU's array, which keeps the last
+ * call's contents: calls are serialised per device by the library; a second PROCESS has its own array. */
+#define RTX_NOALLOC_SCRATCH_MIB 64
+int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params,
+                            uint8_t* rgb_out, rtx_stats* stats_or_null);
+
 /* Same rows, but the pre-antialiasing 1-sample-per-pixel float image: what the reference's
  * render2d() (:801-833) holds in image[][] before quantisation.  out[rows * width * 3]. */
 int rtx_render_f32(const rtx_scene* scene, const rtx_params* params,

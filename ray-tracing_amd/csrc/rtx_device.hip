@@ -117,7 +117,7 @@ struct rtx_context {
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
     bool rendered = false;
     int nchunks = 0;
-    // Arena mode: every device buffer is carved out of a caller-provided block
+    // Arena mode (rtx_render_rgb8_noalloc): every device buffer is carved out of a caller-provided block
     // (the library's static scratch array) instead of hipMalloc; nothing is created or freed on the device.
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
@@ -685,6 +685,36 @@ static int render_multi(const rtx_scene* scene, const rtx_params* params, int ng
     } catch (const std::bad_alloc&) { return RTX_E_OOM; }                                     \
     catch (...) { g_last_hip_error = "unexpected C++ exception"; return RTX_E_HIP; }
 
+// ------------------------------------------------------------------------------------------------
+// rtx_render_rgb8_noalloc: the one-shot render with every device buffer in a static array
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kScratchBytes = (size_t)RTX_NOALLOC_SCRATCH_MIB << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// `scratch` above is a host-side stand-in in host code: its device address is asked for once per device
+// (each GPU holds its own copy of the array at its own address) and only that pointer is ever used.
+constexpr int kMaxScratchDevices = 64;
+struct ScratchDev { void* ptr = nullptr; bool ready = false; std::mutex busy; };
+static ScratchDev g_scratch[kMaxScratchDevices];
+static std::mutex g_scratch_init;
+
+static int scratch_for_device(int dev, ScratchDev** out)
+{
+    if (dev < 0 || dev >= kMaxScratchDevices) return RTX_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g_scratch_init);
+    ScratchDev& sd = g_scratch[dev];
+    if (!sd.ready) {
+        HIPCHK(hipSetDevice(dev));
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p & 255) != 0) { g_last_hip_error = "hipGetSymbolAddress(scratch): null or misaligned address"; return RTX_E_HIP; }
+        sd.ptr = p;
+        sd.ready = true;
+    }
+    *out = &sd;
+    return RTX_OK;
+}
+
 extern "C" {
 
 int rtx_device_count(void)
@@ -795,6 +825,42 @@ int rtx_render_f32(const rtx_scene* scene, const rtx_params* params, float* out,
     int rc = validate(scene, params);
     if (rc) return rc;
     return render_one(scene, params, nullptr, out, stats);
+}
+
+int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params, uint8_t* out, rtx_stats* stats)
+{
+    if (!out) return RTX_E_INVALID_ARG;
+    int rc = validate(scene, params);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RTX_E_NO_DEVICE;
+    int dev = params->device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) return RTX_E_INVALID_ARG;
+    RTX_TRY
+    ScratchDev* sd = nullptr;
+    if ((rc = scratch_for_device(dev, &sd))) return rc;
+    // one call at a time per device: every call on a GPU works in that GPU's one array
+    std::lock_guard<std::mutex> lk(sd->busy);
+    rtx_context* c = new (std::nothrow) rtx_context();  // host object only
+    if (!c) return RTX_E_OOM;
+    c->arena = static_cast<char*>(sd->ptr);
+    c->arena_cap = kScratchBytes;
+    rtx_params p = *params;
+    p.device = dev;
+    p.flags &= ~(uint32_t)RTX_F_TIME_KERNELS;  // per-kernel timing needs events: not in this variant
+    try {
+        rc = context_create_impl(scene, &p, c);
+        if (rc == RTX_E_TOO_LARGE)
+            g_last_hip_error = "rtx_render_rgb8_noalloc: scene records + float image + one row of ray queues exceed the " +
+                               std::to_string(RTX_NOALLOC_SCRATCH_MIB) + " MiB static scratch";
+        if (!rc) rc = context_render_impl(c, nullptr, nullptr);
+        if (!rc) rc = rtx_context_read_rgb8(c, out);
+        if (!rc && stats) rc = context_stats_impl(c, stats);
+    } catch (...) { rtx_context_destroy(c); throw; }
+    rtx_context_destroy(c);  // waits for the stream; nothing on the device to free
+    return rc;
+    RTX_CATCH
 }
 
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)

@@ -127,6 +127,7 @@ SYMBOLS = {
     "rtx_context_read_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rtx_context_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtx_band_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "rtx_render_rgb8_noalloc": (C.c_int, [C.POINTER(SceneView), C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]),
     "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
@@ -217,6 +218,15 @@ def render_rgb8(scene, params, ngpus=1):
     out = np.zeros((rows, params.width, 3), dtype=np.uint8)
     st = Stats()
     _check(lib().rtx_render_rgb8(scene.ptr, C.byref(params), ngpus, out.ctypes.data, C.byref(st)), "rtx_render_rgb8")
+    return out, st
+
+
+def render_rgb8_noalloc(scene, params):
+    """rtx_render_rgb8_noalloc: the one-shot render out of the library's static device scratch (no hipMalloc)."""
+    rows = params.height if params.nranks <= 1 else _nrows(params)
+    out = np.zeros((rows, params.width, 3), dtype=np.uint8)
+    st = Stats()
+    _check(lib().rtx_render_rgb8_noalloc(scene.ptr, C.byref(params), out.ctypes.data, C.byref(st)), "rtx_render_rgb8_noalloc")
     return out, st
 
 
