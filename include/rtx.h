@@ -48,7 +48,7 @@ typedef struct rtx_sphere {
 } rtx_sphere;
 
 /* raytracing.cpp:43-49  `struct plane` (40 B).  Parsed (:886-895) but never traced by the
- * reference: accepted and ignored here too. */
+ * reference: accepted and ignored here too, unless RTX_F_TRACE_PLANES asks for them. */
 typedef struct rtx_plane {
     rtx_vec3 normal, color;
     float    d, reflectivity, transparency, refractive_index;
@@ -82,7 +82,7 @@ typedef struct rtx_polygon {
 typedef struct rtx_scene {
     const rtx_sphere*   spheres;    int32_t nspheres;     /* :98,  :106 */
     const rtx_triangle* triangles;  int32_t ntriangles;   /* :100, :108 */
-    const rtx_plane*    planes;     int32_t nplanes;      /* :99,  :107  (ignored, F7) */
+    const rtx_plane*    planes;     int32_t nplanes;      /* :99,  :107  (ignored, F7; traced with RTX_F_TRACE_PLANES) */
     const rtx_light*    lights;     int32_t nlights;      /* :102, :110 */
     rtx_vec3 camera, vrp, vpn, up;                        /* :103  `vcs` */
     rtx_vec3 ambient;                                     /* :104 */
@@ -120,6 +120,16 @@ typedef struct rtx_params {
 #define RTX_F_SERIAL       32u  /* enqueue every kernel of the frame on the caller's stream, in order: no side streams, no
                                    fork / join events, one set of shadow-queue buffers.  Same image; kernel durations do
                                    not overlap, which is what a per-kernel roofline needs (bench.py). */
+#define RTX_F_TRACE_PLANES 128u /* OPT-IN EXTENSION, off by default: also trace the scene's planes.  The reference parses planes
+                                   (:886-895) and never traces them (:382-434), so parity images need this off.
+                                   With it, intersectplane (:275-287) runs after the polygons in file order (strict <, as
+                                   every kind); the hit takes the triangle's facing normal and shading forms with, a plane
+                                   having no such fields (:43-49), diffcolor = color, speccoeff = 0, specexpo = 1; like
+                                   polygons, planes cast no shadows.  oracle/rt_oracle.c implements the same (ORC_TRACE_PLANES). */
+#define RTX_F_TRI_MOLLER_TRUMBORE 256u /* OPT-IN, NON-PARITY fast mode: triangles are tested with Moller-Trumbore instead of
+                                   the reference's area test with its absolute 0.01 tolerance (:329-366).  Edge
+                                   pixels differ from the reference's; the mismatch rate is reported by the tests, never
+                                   counted as parity. */
 #define RTX_F_COUNT_EXEC   64u  /* run the counting instantiations of the PRODUCTION intersection kernels (slower: atomics):
                                    what they actually evaluate, by kind -> rtx_stats.exec_counts.  Same image. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):

@@ -129,9 +129,55 @@ int orc_intersect_sphere(V o, V d, const rtx_sphere* s, V* normal, float* t0, fl
     return 1;
 }
 
+/* Opt-in extensions of the build (NOT reference behaviour; both off by default, see rt_oracle.h) */
+static int g_flags = 0;
+void orc_set_flags(int flags) { g_flags = flags; }
+int orc_get_flags(void) { return g_flags; }
+
+/* ORC_TRI_MT: Moller-Trumbore in plain binary32 operations, the order of triangle_test_mt (rtx_math.hip.h);
+ * the facing normal stays the reference's (unit `cross`, sign of vd, rt.cpp:343-347).  No reference counterpart. */
+static int intersect_triangle_mt(V o, V dir, const rtx_triangle* s, V* normal, float* t)
+{
+    V v1 = mkv(s->u.x - s->v.x, s->u.y - s->v.y, s->u.z - s->v.z);
+    V v2 = mkv(s->w.x - s->v.x, s->w.y - s->v.y, s->w.z - s->v.z);
+    V cr = mkv(v1.y * v2.z - v2.y * v1.z, v2.x * v1.z - v1.x * v2.z, v1.x * v2.y - v2.x * v1.y);
+    orc_normalize(&cr);
+    float vd = dot(cr, dir);
+    if (vd > 0) { normal->x = -cr.x; normal->y = -cr.y; normal->z = -cr.z; } else *normal = cr;
+    float e1x = s->v.x - s->u.x, e1y = s->v.y - s->u.y, e1z = s->v.z - s->u.z;
+    float e2x = s->w.x - s->u.x, e2y = s->w.y - s->u.y, e2z = s->w.z - s->u.z;
+    float px = dir.y * e2z - dir.z * e2y, py = dir.z * e2x - dir.x * e2z, pz = dir.x * e2y - dir.y * e2x;
+    float det = e1x * px + e1y * py + e1z * pz;
+    if (det == 0.0f) return 0;
+    float inv = 1.0f / det;
+    float tx = o.x - s->u.x, ty = o.y - s->u.y, tz = o.z - s->u.z;
+    float uu = (tx * px + ty * py + tz * pz) * inv;
+    if (uu < 0.0f || uu > 1.0f) return 0;
+    float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    float vv = (dir.x * qx + dir.y * qy + dir.z * qz) * inv;
+    if (vv < 0.0f || uu + vv > 1.0f) return 0;
+    *t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+    if (*t < 0.0f) return 0;
+    return 1;
+}
+
+/* rt.cpp:275-287 intersectplane (dead code in the reference; traced only with ORC_TRACE_PLANES) */
+int orc_intersect_plane(V o, V dir, const rtx_plane* p, float* t, float* vd_out)
+{
+    V n = p->normal;
+    orc_normalize(&n);
+    float vd = dot(n, dir);
+    if (vd_out) *vd_out = vd;
+    if (vd == 0) return 0;
+    *t = -(dot(n, o) + p->d) / (vd);
+    if (*t < 0) return 0;
+    return 1;
+}
+
 /* rt.cpp:329-366: plane hit + "three sub-areas sum to the area within 0.01" (not Moller-Trumbore) */
 int orc_intersect_triangle(V o, V dir, const rtx_triangle* s, V* normal, float* t)
 {
+    if (g_flags & ORC_TRI_MT) return intersect_triangle_mt(o, dir, s, normal, t);
     V v1 = mkv(s->u.x - s->v.x, s->u.y - s->v.y, s->u.z - s->v.z);
     V v2 = mkv(s->w.x - s->v.x, s->w.y - s->v.y, s->w.z - s->v.z);
     V cross = mkv(v1.y * v2.z - v2.y * v1.z, v2.x * v1.z - v1.x * v2.z, v1.x * v2.y - v2.x * v1.y);
@@ -243,6 +289,7 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
     const rtx_sphere* s = NULL;
     const rtx_triangle* tr = NULL;
     const rtx_polygon* pg = NULL;
+    const rtx_plane* pl = NULL;
     V pix, normal = mkv(0, 0, 0);
     int objectfound = 0, transformed = 0;
     int ob = 0; /* 0 none, 1 sphere, 2 triangle, 3 polygon */
@@ -302,6 +349,23 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
             }
         }
     }
+    /* ORC_TRACE_PLANES (extension; the reference never traces planes): after the polygons, file order, strict <;
+     * intersectplane returns no normal: the triangle's facing rule (:343-347) on the normalised plane normal */
+    for (int i = 0; (g_flags & ORC_TRACE_PLANES) && i < sc->nplanes; i++) {
+        float t = MAX_T, vd = 0;
+        if (orc_intersect_plane(rayorigin, raydir, &sc->planes[i], &t, &vd)) {
+            if (t < nearest) {
+                nearest = t;
+                pl = &sc->planes[i];
+                normal = pl->normal;
+                orc_normalize(&normal);
+                if (vd > 0) { normal.x = -normal.x; normal.y = -normal.y; normal.z = -normal.z; }
+                ob = 4;
+                objectfound = 1;
+                transformed = 0;
+            }
+        }
+    }
     if (!objectfound) return pix; /* :436-438, no ambient */
     if (cnt) cnt->hits++;
     V intpoint = mkv(rayorigin.x + nearest * raydir.x, rayorigin.y + nearest * raydir.y, rayorigin.z + nearest * raydir.z);
@@ -324,9 +388,12 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
         } else if (ob == 2) {
             secondary(sc, max_depth, depth, cnt, raydir, normal, intpoint, bias,
                       tr->reflectivity, tr->transparency, tr->refractive_index, tr->color, 0, &pix);
-        } else { /* :527-556: the triangle block again with the polygon's material */
+        } else if (ob == 3) { /* :527-556: the triangle block again with the polygon's material */
             secondary(sc, max_depth, depth, cnt, raydir, normal, intpoint, bias,
                       pg->reflectivity, pg->transparency, pg->refractive_index, pg->color, 0, &pix);
+        } else { /* extension: the triangle block with the plane's material */
+            secondary(sc, max_depth, depth, cnt, raydir, normal, intpoint, bias,
+                      pl->reflectivity, pl->transparency, pl->refractive_index, pl->color, 0, &pix);
         }
     }
     /* :560-641 */
@@ -369,8 +436,10 @@ V orc_raytrace(const rtx_scene* sc, int max_depth, V rayorigin, V raydir, int de
                 speccoeff = s->speccoeff; diffcolor = s->diffcolor; specexpo = s->specexpo;
             } else if (ob == 2) { /* :613-626: no normalisation of either direction */
                 speccoeff = tr->speccoeff; diffcolor = tr->diffcolor; specexpo = tr->specexpo;
-            } else { /* :627-639: the same form for polygons */
+            } else if (ob == 3) { /* :627-639: the same form for polygons */
                 speccoeff = pg->speccoeff; diffcolor = pg->diffcolor; specexpo = pg->specexpo;
+            } else { /* extension: a plane has no such fields (:43-49): diffcolor = color, speccoeff = 0, specexpo = 1 */
+                speccoeff = mkv(0, 0, 0); diffcolor = pl->color; specexpo = 1.0f;
             }
             float ndoti2 = 2 * (dot(ldir, normal));
             V reflectedray = mkv(ndoti2 * normal.x - ldir.x, ndoti2 * normal.y - ldir.y, ndoti2 * normal.z - ldir.z);

@@ -35,6 +35,15 @@ int orc_intersect_triangle(rtx_vec3 o, rtx_vec3 d, const rtx_triangle* s, rtx_ve
 /* rt.cpp:289-325 */
 float orc_find_area_polygon(const rtx_polygon* p, const rtx_vec3* verts, rtx_vec3 point);
 int orc_intersect_polygon(rtx_vec3 o, rtx_vec3 d, const rtx_polygon* p, const rtx_vec3* verts, rtx_vec3* normal, float* t);
+/* rt.cpp:275-287 (dead code in the reference: planes are parsed, never traced) */
+int orc_intersect_plane(rtx_vec3 o, rtx_vec3 d, const rtx_plane* p, float* t, float* vd_out);
+/* Opt-in extensions the build defines beyond the reference (include/rtx.h RTX_F_TRACE_PLANES,
+ * RTX_F_TRI_MOLLER_TRUMBORE), restated here so the GPU path can be checked in those modes too.  Process-wide; 0 =
+ * the reference's behaviour, which is what every parity test and fixture uses. */
+#define ORC_TRACE_PLANES 1
+#define ORC_TRI_MT 2
+void orc_set_flags(int flags);
+int  orc_get_flags(void);
 /* rt.cpp:371-647 */
 rtx_vec3 orc_raytrace(const rtx_scene* sc, int max_depth, rtx_vec3 o, rtx_vec3 d, int depth, orc_counts* cnt);
 /* rt.cpp:792-794: one channel */

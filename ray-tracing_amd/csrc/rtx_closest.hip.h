@@ -80,6 +80,17 @@ __device__ __forceinline__ bool ray_abnormal(F3 o, F3 d, F3 nd, float guard)
     return !ok;
 }
 
+// A ray with a NaN in its origin or direction -- what total internal reflection leaves behind: sqrtf(k < 0) at
+// raytracing.cpp:483-485 makes every component of the refracted direction NaN -- hits nothing in the reference's
+// closest-hit loops: every t it computes is NaN (sphere: b and c are sums with the NaN in them, :209-216; triangle and
+// polygon: t = .../vd, :345, :313; 0 * NaN is NaN too, so no zero coefficient saves a term) and `t < nearest` (:392,
+// :411, :426) is false for NaN.  Such rays are answered "miss" without a single test instead of taking the
+// every-primitive path of the rays the filter cannot analyse (5 %-refractive C4: 84 ms of a 119 ms frame was that).
+__device__ __forceinline__ bool ray_dead(F3 o, F3 d)
+{
+    return (o.x != o.x) || (o.y != o.y) || (o.z != o.z) || (d.x != d.x) || (d.y != d.y) || (d.z != d.z);
+}
+
 constexpr float kDirScale = 1.0f + 1.0f / 262144.0f;  // (1 + 2^-18), see rtx_bounds.cpp
 
 // Block-cooperative staging of one tile of filter records; the tail of the last group is padded
@@ -117,7 +128,7 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
         const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
         float t, vd;
         int exitp = 0;
-        const bool hit = triangle_test_edge(o, d, T, e0, e1, t, vd, h.nearest, ex ? &exitp : nullptr);
+        const bool hit = triangle_test_edge(o, d, T, e0, e1, t, vd, h.nearest, ex ? &exitp : nullptr, S.mt != 0);
         if (ex) ex_tri(ex, exitp);
         if (hit) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
@@ -125,7 +136,7 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
     } else {
         const float4* p = S.phot + (size_t)k * 5;
         float t;
-        ex_add(ex, EX_POLY, (unsigned)__float_as_int(p[1].z));
+        ex_add(ex, EX_POLY, (unsigned)max(__float_as_int(p[1].z), 1));
         if (polygon_test(o, d, p[0], p[1], S.poly_verts, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
@@ -165,7 +176,7 @@ __device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, co
         T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
         float t, vd;
         int exitp = 0;
-        const bool hit = pass && triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr);
+        const bool hit = pass && triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr, S.mt != 0);
         if (ex && pass) ex_tri(ex, exitp);
         if (hit) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
@@ -173,7 +184,7 @@ __device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, co
     } else {
         const float4 q1 = bcast4(pr.q1, u);
         float t;
-        if (pass) ex_add(ex, EX_POLY, (unsigned)__float_as_int(q1.z));
+        if (pass) ex_add(ex, EX_POLY, (unsigned)max(__float_as_int(q1.z), 1));
         if (pass && polygon_test(o, d, q0, q1, S.poly_verts, t)) {
             if (t < h.nearest) { h.nearest = t; h.best = k; h.tflag = 0; }
         }
@@ -306,12 +317,13 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
 {
     const int lane = threadIdx.x & 63;
     const int q = base + threadIdx.x;
-    const bool live = q < n;
-    const int i = live ? q : 0;
+    const bool inq = q < n;
+    const int i = inq ? q : 0;
     const int ii = i;
     F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
     F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
     F3 nd = normalized(d);
+    const bool live = inq && !ray_dead(o, d);  // NaN rays miss everything: they sit the kernel out and are written as misses
     const bool abn = ray_abnormal(o, d, nd, S.guard);
     const bool use = live && !abn;
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
@@ -457,7 +469,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
         atomicAdd(S.pstat + 0, 1ull); atomicAdd(S.pstat + 1, P.ok ? 1ull : 0ull);
         atomicAdd(S.pstat + 2, (unsigned long long)pk_batches); atomicAdd(S.pstat + 3, (unsigned long long)pk_surv);
     }
-    if (live) {
+    if (inq) {
         L.t[i] = h.nearest;
         L.prim[i] = (h.best < 0) ? -1 : (h.best | h.tflag);
     }
@@ -508,7 +520,7 @@ __device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F
         }
         return sphere_test(to, td, q0.x, q0.y, q0.z, q0.w, t) ? (xf ? 3 : 1) : 0;
     } else if (k >= S.ns + S.nt) {
-        ex_add(ex, EX_POLY, (unsigned)__float_as_int(q1.z));
+        ex_add(ex, EX_POLY, (unsigned)max(__float_as_int(q1.z), 1));
         return polygon_test(o, d, q0, q1, S.poly_verts, t) ? 2 : 0;
     } else {
         TriRec T;
@@ -519,7 +531,7 @@ __device__ __forceinline__ int exact_hit(const SceneDev& S, int k, F3 o, F3 d, F
         T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
         float vd;
         int exitp = 0;
-        const bool hit = triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr);
+        const bool hit = triangle_test(o, d, T, t, vd, ex ? &exitp : nullptr, S.mt != 0);
         if (ex) ex_tri(ex, exitp);
         return hit ? 2 : 0;
     }
@@ -609,13 +621,14 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     const int myray = lane & (R - 1), part = lane / R;
     // ---- the wave's rays: lanes < R own one each ----
     const int q = q0 + lane;
-    const bool live = lane < R && q < n;
-    const int i = live ? q : 0;
+    const bool inq = lane < R && q < n;
+    const int i = inq ? q : 0;
     F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
     F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
     F3 nd = normalized(d);
+    const bool live = inq && !ray_dead(o, d);  // NaN rays (total internal reflection) miss everything: no traversal
     const bool abn = live && ray_abnormal(o, d, nd, S.guard);
-    if (live) ex_add(ex, EX_RAYS);
+    if (inq) ex_add(ex, EX_RAYS);
     if (lane < R) {
         W.rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
         W.rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
@@ -796,7 +809,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
             atomicAdd(S.pstat + 3, (unsigned long long)tested);
         }
     }
-    if (live) {
+    if (inq) {
         L.t[i] = nearest;
         L.prim[i] = (best < 0) ? -1 : (best | tflag);
     }
@@ -825,14 +838,15 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 64 + lane;  // the four waves hold the same 64 rays
-    const bool live = i < n;
-    const int ii = live ? i : 0;
+    const bool inq = i < n;
+    const int ii = inq ? i : 0;
     F3 o = f3(L.ox[ii], L.oy[ii], L.oz[ii]);
     F3 d = f3(L.dx[ii], L.dy[ii], L.dz[ii]);
     F3 nd = normalized(d);
+    const bool live = inq && !ray_dead(o, d);
     const bool abn = ray_abnormal(o, d, nd, S.guard);
     const bool use = live && !abn;
-    if (live && w == 0) ex_add(ex, EX_RAYS);
+    if (inq && w == 0) ex_add(ex, EX_RAYS);
     F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
     F3 fd = use ? f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
     unsigned accinit = (live && abn) ? 0u : 0xFFFFFFFFu;
@@ -867,7 +881,7 @@ __device__ __forceinline__ void closest_thin(const SceneDev& S, const LevelDev& 
     float* rx = reinterpret_cast<float*>(tile) + 512;
     rt[threadIdx.x] = h.nearest; rb[threadIdx.x] = h.best; rx[threadIdx.x] = h.txf;
     __syncthreads();
-    if (w == 0 && live) {
+    if (w == 0 && inq) {
         float m = kMaxT;
         int best = -1, flag = 0;
         for (int p = 0; p < 4; p++) {

@@ -156,8 +156,10 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
     if (p->max_depth + 1 > RTX_MAX_LEVELS) return RTX_E_TOO_LARGE;
     if ((int64_t)p->width * p->height > (int64_t)1 << 30) return RTX_E_TOO_LARGE;
     if (int rc = validate_scene(sc)) return rc;
-    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
-    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons >= ((int64_t)1 << kPoolPrimBits)) return RTX_E_TOO_LARGE;  // closest_pool's list entries
+    if ((p->flags & RTX_F_TRACE_PLANES) && sc->nplanes && !sc->planes) return RTX_E_INVALID_ARG;
+    const int64_t npl = (p->flags & RTX_F_TRACE_PLANES) ? sc->nplanes : 0;
+    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons + npl >= (int64_t)kTFlag) return RTX_E_TOO_LARGE;
+    if ((int64_t)sc->nspheres + sc->ntriangles + sc->npolygons + npl >= ((int64_t)1 << kPoolPrimBits)) return RTX_E_TOO_LARGE;  // closest_pool's list entries
     if (sc->nlights > 65535) return RTX_E_TOO_LARGE;  // gridDim.y
     int nr = p->nranks <= 1 ? 1 : p->nranks;
     int rk = p->nranks <= 1 ? 0 : p->rank;
@@ -196,7 +198,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     const int ntrace = (int)c->trace_rows.size();
 
     PackedScene P;
-    pack_scene(*scene, W, H, P);
+    pack_scene(*scene, W, H, P, params->flags);
     c->singular = P.singular;
     c->fanout = P.max_fanout;
     c->levels = (P.max_fanout == 0) ? 1 : params->max_depth + 1;
@@ -235,7 +237,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             rtx_polygon* pg = nullptr; float* pv = nullptr;
             if ((rc = c->upload(&pg, P.poly))) return rc;
             if ((rc = c->upload(&pv, P.poly_verts))) return rc;
-            c->S.poly = pg; c->S.poly_verts = reinterpret_cast<const float4*>(pv); c->S.np = (int)P.poly.size();
+            c->S.poly = pg; c->S.poly_verts = reinterpret_cast<const float4*>(pv); c->S.np = (int)P.poly.size();  // + planes, if traced
+            c->S.mt = (params->flags & RTX_F_TRI_MOLLER_TRUMBORE) ? 1 : 0;
         }
         c->S.ns = (int)P.sph.size(); c->S.nt = (int)P.tri.size(); c->S.nl = (int)P.lights.size();
         c->S.ambient = {P.ambient.x, P.ambient.y, P.ambient.z};

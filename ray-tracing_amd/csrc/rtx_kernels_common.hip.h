@@ -15,7 +15,9 @@ constexpr int kTFlag = 1 << 30;      // the reference's `transformed` flag, carr
 // ------------------------------------------------------------------------------------------------
 struct SceneDev {
     int ns, nt, nl;
-    int np;                       // polygons: primitive index ns + nt + i, traced after the triangles (:421-434)
+    int mt;                       // RTX_F_TRI_MOLLER_TRUMBORE: tri_hot / phot hold the Moller-Trumbore records (rtx_math.hip.h)
+    int np;                       // polygons: primitive index ns + nt + i, traced after the triangles (:421-434); with
+                                  // RTX_F_TRACE_PLANES the planes follow them as records with vertex count -1
     const rtx_polygon* poly;      // [np] raw records (materials)
     const float4* poly_verts;     // vertices, x y z 0; a polygon's run starts at its hot record's first_vertex
     const float4* sph_hot;        // [ns]  cx cy cz r^2
@@ -112,6 +114,15 @@ __device__ __forceinline__ float4 bcast4(float4 v, int u)
 __device__ __forceinline__ bool polygon_test(F3 o, F3 dir, float4 q0, float4 q1, const float4* verts, float& t)
 {
     const int first = __float_as_int(q1.y), cnt = __float_as_int(q1.z);
+    if (cnt == -1) {
+        // RTX_F_TRACE_PLANES: intersectplane, raytracing.cpp:275-287 with normalize(p.normal) (:277) done on the host;
+        // q0 = { unit normal, d as given }
+        const float vd = q0.x * dir.x + q0.y * dir.y + q0.z * dir.z;
+        if (vd == 0.0f) return false;
+        t = -((q0.x * o.x + q0.y * o.y + q0.z * o.z) + q0.w) / vd;
+        if (t < 0.0f) return false;
+        return true;
+    }
     if (cnt < 1) return false;
     t = -((q0.x * o.x + q0.y * o.y + q0.z * o.z) + q0.w) / (q0.x * dir.x + q0.y * dir.y + q0.z * dir.z);  // :313
     if (t < 0.0f) return false;
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, cons
     for (int k = 0; k < S.nt; k++) {
         TriRec T = load_tri(S.tri_hot, k);
         float t = 0.0f, vd;
-        bool h = triangle_test(o, d, T, t, vd);
+        bool h = triangle_test(o, d, T, t, vd, nullptr, S.mt != 0);
         if (COUNT) cnt[(vd == 0.0f || t < 0.0f) ? 3 : 2]++;
         if (h) {
             if (t < nearest) {

@@ -107,11 +107,35 @@ struct TriRec {
 
 // raytracing.cpp:338-365 with the ray-independent head precomputed.  Returns what
 // intersecttriangle returns (true also on NaN); vd is handed back for the facing normal (:343-347).
+// RTX_F_TRI_MOLLER_TRUMBORE (opt-in, NOT the reference's test: SURVEY.md F8): Moller-Trumbore on the record packed for it
+// (rtx_pack.cpp: u in {vx,vy,vz}, e1 = v - u in {wx,wy,wz}, e2 = w - u in {v1x,v1y,v1z}; q0 keeps the reference's unit normal
+// for the facing rule).  No epsilon: det == 0 is the only parallel case, as vd == 0 is the reference's; hits need t >= 0 as
+// the reference's do.  Plain binary32 operations in this order, so oracle/rt_oracle.c (ORC_TRI_MT) gives the same bits.
+__device__ __forceinline__ bool triangle_test_mt(F3 o, F3 dir, const TriRec& T, float& t, float& vd)
+{
+    vd = T.nx * dir.x + T.ny * dir.y + T.nz * dir.z;
+    const float e1x = T.wx, e1y = T.wy, e1z = T.wz, e2x = T.v1x, e2y = T.v1y, e2z = T.v1z;
+    const float px = dir.y * e2z - dir.z * e2y, py = dir.z * e2x - dir.x * e2z, pz = dir.x * e2y - dir.y * e2x;
+    const float det = e1x * px + e1y * py + e1z * pz;
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const float tx = o.x - T.vx, ty = o.y - T.vy, tz = o.z - T.vz;
+    const float uu = (tx * px + ty * py + tz * pz) * inv;
+    if (uu < 0.0f || uu > 1.0f) return false;
+    const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    const float vv = (dir.x * qx + dir.y * qy + dir.z * qz) * inv;
+    if (vv < 0.0f || uu + vv > 1.0f) return false;
+    t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+    if (t < 0.0f) return false;
+    return true;
+}
+
 // exitp (counting builds only; the pointer is a compile-time null elsewhere): where the test left --
 // 0 at vd == 0 or t < 0 (13 FLOP), 1 at the nearest-t cull (13), 3 at the edge filter (38), 2 after the areas (76).
-__device__ __forceinline__ bool triangle_test(F3 o, F3 dir, const TriRec& T, float& t, float& vd, int* exitp = nullptr)
+__device__ __forceinline__ bool triangle_test(F3 o, F3 dir, const TriRec& T, float& t, float& vd, int* exitp = nullptr, const bool mt = false)
 {
     if (exitp) *exitp = 0;
+    if (mt) { if (exitp) *exitp = 2; return triangle_test_mt(o, dir, T, t, vd); }  // wave-uniform
     vd = T.nx * dir.x + T.ny * dir.y + T.nz * dir.z;
     if (vd == 0.0f) return false;
     t = -((T.nx * o.x + T.ny * o.y + T.nz * o.z) + T.d) / vd;
@@ -137,9 +161,13 @@ __device__ __forceinline__ bool triangle_test(F3 o, F3 dir, const TriRec& T, flo
 // tmax: a closest-hit caller that only takes hits with t < nearest passes nearest, and a hit it would drop
 // is reported as a miss before the areas are computed (any-hit callers pass +inf: NaN and every t stay in).
 __device__ __forceinline__ bool triangle_test_edge(F3 o, F3 dir, const TriRec& T, const float4 e0, const float4 e1, float& t, float& vd,
-                                                   const float tmax = __builtin_inff(), int* exitp = nullptr)
+                                                   const float tmax = __builtin_inff(), int* exitp = nullptr, const bool mt = false)
 {
     if (exitp) *exitp = 0;
+    if (mt) {  // wave-uniform; the edge records belong to the area test and are not used
+        if (exitp) *exitp = 2;
+        return triangle_test_mt(o, dir, T, t, vd) && !(t >= tmax);
+    }
     vd = T.nx * dir.x + T.ny * dir.y + T.nz * dir.z;
     if (vd == 0.0f) return false;
     t = -((T.nx * o.x + T.ny * o.y + T.nz * o.z) + T.d) / vd;

@@ -184,9 +184,10 @@ void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32
     out.seg_first.push_back((int32_t)out.cl.size());
 }
 
-void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
+void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P, uint32_t flags)
 {
     P = PackedScene();
+    const bool mt = (flags & RTX_F_TRI_MOLLER_TRUMBORE) != 0, planes = (flags & RTX_F_TRACE_PLANES) != 0;
     int fan = 0;
     for (int i = 0; i < sc.nspheres; i++) {
         const rtx_sphere& s = sc.spheres[i];
@@ -217,6 +218,16 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
                        t.w.x, t.w.y, t.w.z, v1.x,
                        v1.y, v1.z, v2.x, v2.y,
                        v2.z, e.x, e.y, e.z } };
+        if (mt) {
+            // opt-in Moller-Trumbore record (rtx_math.hip.h, triangle_test_mt): u, e1 = v - u, e2 = w - u; the unit
+            // normal, d and the area keep their places (facing rule of the set-up kernel, shadow order below)
+            TriHot m = { { n.x, n.y, n.z, d,
+                           t.u.x, t.u.y, t.u.z, area,
+                           t.v.x - t.u.x, t.v.y - t.u.y, t.v.z - t.u.z, t.w.x - t.u.x,
+                           t.w.y - t.u.y, t.w.z - t.u.z, 0.0f, 0.0f,
+                           0.0f, 0.0f, 0.0f, 0.0f } };
+            h = m;
+        }
         P.tri_hot.push_back(h);
         P.tri_edge.push_back(tri_edge_filter(t));
         P.tri.push_back(t);
@@ -264,6 +275,31 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P)
         P.prim_hot.push_back(r);
         for (int a = 0; a < nv; a++) { P.poly_verts.push_back(vv[a].x); P.poly_verts.push_back(vv[a].y); P.poly_verts.push_back(vv[a].z); P.poly_verts.push_back(0.0f); }
         int f = (pg.reflectivity > 0 ? 1 : 0) + (pg.transparency > 0 ? 1 : 0);
+        if (f > P.max_fanout) P.max_fanout = f;
+    }
+
+    // RTX_F_TRACE_PLANES (opt-in; the reference parses planes and never traces them): each plane rides
+    // behind the polygons as a record with vertex count -1: q0 = { normalize(normal) (:277), d as given }, and a
+    // polygon-shaped material record -- a plane has no diffcolor / speccoeff / specexpo (:43-49), so this build
+    // DEFINES diffcolor = color, speccoeff = 0, specexpo = 1.  Like polygons, planes cast no shadows.
+    for (int i = 0; planes && i < sc.nplanes; i++) {
+        const rtx_plane& pl = sc.planes[i];
+        rtx_vec3 n = pl.normal;
+        normalize(n);
+        rtx_polygon g;
+        std::memset(&g, 0, sizeof g);
+        g.numvertices = -1;
+        g.color = pl.color; g.diffcolor = pl.color; g.specexpo = 1.0f;
+        g.normal = n;
+        g.reflectivity = pl.reflectivity; g.transparency = pl.transparency; g.refractive_index = pl.refractive_index;
+        P.poly.push_back(g);
+        int32_t first = 0, cnt = -1;
+        float ff, fc;
+        std::memcpy(&ff, &first, 4);
+        std::memcpy(&fc, &cnt, 4);
+        TriHot r = { { n.x, n.y, n.z, pl.d, 0.0f, ff, fc, 0.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 } };
+        P.prim_hot.push_back(r);
+        int f = (pl.reflectivity > 0 ? 1 : 0) + (pl.transparency > 0 ? 1 : 0);
         if (f > P.max_fanout) P.max_fanout = f;
     }
 
@@ -375,7 +411,7 @@ extern "C" int rtx_filter_records(const rtx_scene* scene, float* out4, int32_t c
     if (rc) return rc;
     RTX_PACK_TRY
     rtx::PackedScene P;
-    rtx::pack_scene(*scene, 1, 1, P);
+    rtx::pack_scene(*scene, 1, 1, P, 0u);
     const int n = (int)P.bounds.size();  // spheres, triangles, then one always-pass record per polygon
     if (out4) {
         if (capacity < n) return RTX_E_INVALID_ARG;
@@ -395,7 +431,7 @@ extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, i
     if (rc) return rc;
     RTX_PACK_TRY
     rtx::PackedScene P;
-    rtx::pack_scene(*scene, 1, 1, P);
+    rtx::pack_scene(*scene, 1, 1, P, 0u);
     int n = (int)P.aff_shadow.size();
     if (out16) {
         if (capacity < n) return RTX_E_INVALID_ARG;

@@ -116,7 +116,9 @@ struct PackedScene {
 
 int validate_scene(const rtx_scene* sc);  // RTX_OK or RTX_E_INVALID_ARG: pointers, counts, polygon vertex ranges
 rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular);
-void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& out);
+// flags: RTX_F_TRACE_PLANES appends the planes behind the polygons, RTX_F_TRI_MOLLER_TRUMBORE packs the triangles' hot
+// records for triangle_test_mt
+void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& out, uint32_t flags);
 
 }  // namespace rtx
 #endif

@@ -52,6 +52,11 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         } else {
             const float4 q0 = S.phot[(size_t)prim * 5];
             normal = f3(q0.x, q0.y, q0.z);  // :311: the stored normal, negated
+            if (__float_as_int(S.phot[(size_t)prim * 5 + 1].z) == -1) {
+                // a plane (RTX_F_TRACE_PLANES; intersectplane returns no normal): the triangle's facing rule, :343-347
+                const float vd = q0.x * d.x + q0.y * d.y + q0.z * d.z;
+                if (vd > 0.0f) normal = f3(-q0.x, -q0.y, -q0.z);
+            }
             const rtx_polygon& g = S.poly[prim - S.ns - S.nt];
             reflectivity = g.reflectivity; transparency = g.transparency; ri = g.refractive_index;
         }
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(SceneDev S, LevelDev L, const
     for (int k = 0; k < S.nt && !shadow; k++) {
         TriRec T = load_tri(S.tri_hot, k);
         float t = 0.0f, vd;
-        shadow = triangle_test(o, ld, T, t, vd);
+        shadow = triangle_test(o, ld, T, t, vd, nullptr, S.mt != 0);
         if (COUNT) cnt[(vd == 0.0f || t < 0.0f) ? 3 : 2]++;
     }
     L.lit[(size_t)li * L.cap + j] = shadow ? 0 : 1;

@@ -21,7 +21,7 @@ __device__ __forceinline__ bool exact_any(const SceneDev& S, int k, F3 o, F3 ld,
     const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
     float t, vd;
     int exitp = 0;
-    const bool hit = triangle_test_edge(o, ld, T, e0, e1, t, vd, __builtin_inff(), ex ? &exitp : nullptr);
+    const bool hit = triangle_test_edge(o, ld, T, e0, e1, t, vd, __builtin_inff(), ex ? &exitp : nullptr, S.mt != 0);
     if (ex) ex_tri(ex, exitp);
     return hit;
 }

@@ -15,6 +15,8 @@ F_NO_HALO = 8
 F_PACKET_STATS = 16
 F_SERIAL = 32
 F_COUNT_EXEC = 64
+F_TRACE_PLANES = 128
+F_TRI_MOLLER_TRUMBORE = 256
 RTX_EXEC_KINDS = 16
 EXEC_KERNELS = ("k_closest_f", "k_closest_lanes", "k_shadow_pass")
 EXEC_KINDS = ("packet", "cone", "filt", "afilt", "strip", "sph", "sphx", "tri_early", "tri_cull", "tri_full", "poly", "packets_built", "rays", "tri_edge")

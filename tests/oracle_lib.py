@@ -46,10 +46,28 @@ def lib():
         L.orc_intersect_triangle.restype = C.c_int
         L.orc_intersect_triangle.argtypes = [rt.host.Vec3, rt.host.Vec3, C.POINTER(rt.host.Triangle),
                                              C.POINTER(rt.host.Vec3), C.POINTER(C.c_float)]
+        L.orc_set_flags.restype = None
+        L.orc_set_flags.argtypes = [C.c_int]
         L.orc_accept_matrix.restype = None
         L.orc_accept_matrix.argtypes = [SV, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
+
+
+TRACE_PLANES, TRI_MT = 1, 2
+
+
+class flags:
+    """with oracle.flags(oracle.TRACE_PLANES): ...  -- the build's opt-in extensions, off again afterwards."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __enter__(self):
+        lib().orc_set_flags(self.f)
+
+    def __exit__(self, *a):
+        lib().orc_set_flags(0)
 
 
 def render_f32(scene, width, height, max_depth=4, row0=0, row1=None, col0=0, col1=None):

@@ -1,0 +1,78 @@
+"""-m gpu: the build's two opt-in extensions, through the C-ABI, against the oracle running
+the same extension.  Neither is reference behaviour: with the flags off (every other test) planes are inert and
+triangles take the reference's area test."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+from parity import assert_rgb8_parity, raw_equal_mask
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("max_depth", [4, 0])
+def test_planes_opt_in_matches_oracle(rt, oracle, gpu, max_depth):
+    """RTX_F_TRACE_PLANES: intersectplane (raytracing.cpp:275-287) after the polygons, the triangle's facing rule and
+    shading forms, no shadows from planes -- the same definition in oracle/rt_oracle.c (ORC_TRACE_PLANES)."""
+    sc = rt.load_scene(os.path.join(SCENES, "planes.txt"))
+    assert sc.view.nplanes == 3
+    W, H = 160, 120
+    p = rt.Params.make(W, H, max_depth, flags=rt.host.F_TRACE_PLANES)
+    g, st = rt.render_f32(sc, p)
+    with oracle.flags(oracle.TRACE_PLANES):
+        c, cnt = oracle.render_f32(sc, W, H, max_depth)
+        rc, _ = oracle.render_rgb8(sc, W, H, max_depth)
+    assert st.rays_primary + st.rays_secondary == cnt.trace_calls and st.rays_shadow == cnt.shadow_rays and st.hits == cnt.hits
+    assert st.hits >= W * H                      # a plane behind everything: no primary ray misses
+    same = raw_equal_mask(g, c)
+    assert same.mean() >= 0.999, int((~same).sum())
+    rg, _ = rt.render_rgb8(sc, p)
+    assert_rgb8_parity(rg, rc, "planes")
+    # off by default: the planes are inert, as in the reference
+    g0, st0 = rt.render_f32(sc, rt.Params.make(W, H, max_depth))
+    c0, _ = oracle.render_f32(sc, W, H, max_depth)
+    assert raw_equal_mask(g0, c0).mean() >= 0.999 and st0.hits < W * H
+
+
+def test_planes_culled_equals_exact(rt, gpu):
+    sc = rt.load_scene(os.path.join(SCENES, "planes.txt"))
+    for (W, H) in ((800, 450), (200, 120)):
+        a, sa = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=rt.host.F_TRACE_PLANES))
+        b, sb = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=rt.host.F_TRACE_PLANES | rt.host.F_EXACT_ONLY))
+        assert raw_equal_mask(a, b).all()
+        assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
+@pytest.mark.parametrize("name", ["room.txt", "probe.txt"])
+def test_moller_trumbore_mode_matches_its_oracle(rt, oracle, gpu, name):
+    """RTX_F_TRI_MOLLER_TRUMBORE against the oracle's restatement of the same arithmetic (ORC_TRI_MT)."""
+    sc = rt.load_scene(os.path.join(SCENES, name))
+    W, H = 160, 120
+    p = rt.Params.make(W, H, 4, flags=rt.host.F_TRI_MOLLER_TRUMBORE)
+    g, st = rt.render_f32(sc, p)
+    with oracle.flags(oracle.TRI_MT):
+        c, cnt = oracle.render_f32(sc, W, H, 4)
+        rc, _ = oracle.render_rgb8(sc, W, H, 4)
+    assert st.rays_primary + st.rays_secondary == cnt.trace_calls and st.rays_shadow == cnt.shadow_rays
+    assert raw_equal_mask(g, c).mean() >= 0.999
+    rg, _ = rt.render_rgb8(sc, p)
+    assert_rgb8_parity(rg, rc, name + " MT")
+
+
+def test_moller_trumbore_is_a_non_parity_mode(rt, gpu, tmp_path):
+    """The mode is opt-in because it is NOT the reference's test (area sum within an absolute 0.01, raytracing.cpp:362):
+    report how many pixels of the 10k-primitive scene change, and check its own culling (bounding spheres sized for the
+    reference's larger accept region stay conservative) against its exact-only kernels."""
+    p = tmp_path / "c4.txt"
+    rt.scenegen.write_c4(str(p))
+    sc = rt.load_scene(str(p))
+    W, H = 960, 540
+    ref, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
+    mt, sm = rt.render_rgb8(sc, rt.Params.make(W, H, 4, flags=rt.host.F_TRI_MOLLER_TRUMBORE))
+    mtx, sx = rt.render_rgb8(sc, rt.Params.make(W, H, 4, flags=rt.host.F_TRI_MOLLER_TRUMBORE | rt.host.F_EXACT_ONLY))
+    assert np.array_equal(mt, mtx) and (sm.rays_secondary, sm.rays_shadow, sm.hits) == (sx.rays_secondary, sx.rays_shadow, sx.hits)
+    differ = float((ref != mt).any(axis=2).mean())
+    print("Moller-Trumbore vs the reference's area test, C4 at %dx%d: %.3f %% of pixels differ (NON-PARITY mode)" % (W, H, differ * 100))
+    assert 0.0 < differ < 0.10
