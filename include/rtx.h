@@ -179,6 +179,9 @@ typedef struct rtx_stats {
      * 9 ... that ran the three areas (:352-365), 10 polygon fan triangles tested, 11 packets built, 12 rays traced,
      * 13 exact triangle tests that left at the edge filter. */
     uint64_t exec_counts[3][RTX_EXEC_KINDS];
+    uint64_t queue_overflow;    /* secondary rays dropped because a generation's queue was full, since the context was created.
+                                   0 by construction: capacities are the worst case, or (scenes with primitives that both
+                                   reflect and refract) measured by a calibration pass over the very frame the context renders */
 } rtx_stats;
 
 enum {
@@ -274,6 +277,13 @@ int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capa
  * first three vertices, exact-equality coplanarity check, centroid (:913-966).
  * The returned scene owns its arrays; release with rtx_scene_free. */
 int  rtx_scene_load(const char* path, rtx_scene** out);
+/* OPT-IN, not reference behaviour: reads the OLDER, line-per-record grammars the five bundled inp*.txt
+ * were written in, as their own trailing comments document them (inp.txt:15-17, inp-refl.txt:9-11, inp1.txt:46-50,
+ * inp01.txt:36-39), into the same records, so those scenes render as their authors meant them instead of the grey frame
+ * / single disc parseinput makes of them at HEAD.  Fields those grammars never had are defined by this
+ * loader (rtx_host.cpp: diffcolor = color, speccoeff 0.5, specexpo 20, ambient 0.05); a `cuboid` becomes 12 triangles.
+ * rtx_scene_load stays the contract; the CLI selects this one with --legacy-grammar.  Release with rtx_scene_free. */
+int  rtx_scene_load_legacy(const char* path, rtx_scene** out);
 void rtx_scene_free(rtx_scene* scene);
 /* "P6\n%i %i 255\n" + bytes, as raytracing.cpp:786-797. */
 int  rtx_write_ppm(const char* path, int32_t width, int32_t height, const uint8_t* rgb);

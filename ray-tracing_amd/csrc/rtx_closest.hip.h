@@ -900,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 {
     __shared__ float4 tile[kTile];  // 16 KiB: thin tiles / the four waves' bitmaps (2 KiB) and candidate lists (2 KiB)
     static_assert((kSegPrims / 32 + 512) * 4 * (kBlock / 64) <= kTile * 16, "bitmaps and lists fit");
-    const int n = *nrays;
+    const int n = min(*nrays, L.cap);
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
@@ -925,7 +925,7 @@ template <bool EX = false>
 __global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
 {
     __shared__ PoolLds pool[kBlock / 64];
-    const int n = *nrays;
+    const int n = min(*nrays, L.cap);
     const int w = threadIdx.x >> 6;
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;

@@ -121,6 +121,8 @@ struct rtx_context {
     // (the library's static scratch array) instead of hipMalloc; nothing is created or freed on the device.
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    int* d_overflow = nullptr;              // rays k_setup could not place (a level's capacity exceeded): 0 by construction
+    bool calibrated = false;                // level capacities come from the calibration pass (fan-out 2 scenes)
     bool serial = false;                    // RTX_F_SERIAL / arena mode: everything on the caller's stream, no side streams, no fork/join events
 
     template <typename T> int dalloc(T** p, size_t n)
@@ -166,6 +168,8 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
     if (rk < 0 || rk >= nr) return RTX_E_INVALID_ARG;
     return RTX_OK;
 }
+
+static int calibrate_counts(rtx_context* c, int* d_blk);
 
 static int context_create_impl(const rtx_scene* scene, const rtx_params* params, rtx_context* c)
 {
@@ -370,61 +374,159 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     while (nl1 * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
     c->nbins = (int)nl1 * c->binG * c->binG;
     c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
-    // Device bytes of the ray queues for chunks of `rows` rows, allocation by allocation as below (arena mode
-    // rounds every allocation up to 256 bytes).  Level k holds at most fanout^k rays per level-0 ray.
-    auto plan = [&](int64_t rows) -> double {
-        auto al = [&](double b) { return c->arena ? std::ceil(b / 256.0) * 256.0 : b; };
-        double tot = 0, cap = (double)rows * W;
+    // ---- ray-queue capacities -----------------------------------------------------------------------------------
+    // Level k of a chunk holds at most fanout^k rays per level-0 ray.  With fan-out 1 that bound is the pixel count and
+    // is used as it is.  With fan-out 2 (some primitive both reflects and refracts) it is 31x the pixels at depth 5 and
+    // 255x at depth 8 while the rays that exist are a few tenths of a pixel count per level: there the capacities come
+    // from a CALIBRATION pass at creation -- a context renders one fixed frame, so its ray counts per level and row
+    // block are a property of the context: trace closest hit + set-up (no shadows, no shading) once in worst-case
+    // sized blocks of r_cal rows, keep the per-block counts, and size every level for the largest chunk of the final
+    // layout (chunks are whole numbers of calibration blocks, so their counts are sums of measured ones: exact).
+    // k_setup still refuses to write past a level's capacity and reports it (rtx_stats.queue_overflow), and every
+    // consumer clamps the live count to the capacity: a wrong count costs rays, never memory safety.
+    struct Caps { std::vector<size_t> cap; };
+    auto worst_caps = [&](int64_t rows) {
+        Caps cp; cp.cap.resize(levels);
+        double cap = (double)rows * W;
+        for (int k = 0; k < levels; k++) { cp.cap[k] = (size_t)cap; cap *= fan; }
+        return cp;
+    };
+    // Device bytes of the ray queues for these capacities, allocation by allocation as alloc_levels / alloc_shadow do
+    // (arena mode rounds every allocation up to 256 bytes); nchunks only sizes the per-chunk counters.
+    auto plan_levels = [&](const Caps& cp, bool with_lit) -> double {
+        auto al = [&](double b) { return c->arena ? std::ceil(std::max(b, 1.0) / 256.0) * 256.0 : b; };
+        double tot = 0;
         for (int k = 0; k < levels; k++) {
-            tot += 18.0 * al(cap * 4.0) + (k ? al(cap * 12.0) : 0.0) + al(cap * (double)nl1);
-            if (k + 1 < levels) cap *= fan;
+            const double cap = (double)cp.cap[k];
+            tot += 18.0 * al(cap * 4.0) + (k ? al(cap * 12.0) : 0.0) + (with_lit ? al(cap * (double)nl1) : 0.0);
         }
-        const double qcap = cap * (double)nl1 + (double)c->qpad;
-        const double nb = (double)c->nbins, ng = std::ceil(nb / 1024.0);
-        tot += nlanes * (2.0 * al(qcap * 16.0) + 2.0 * al(nb * 4.0) + al(qcap * 4.0) + 2.0 * al(ng * 4.0));
-        const double nch = ntrace ? std::ceil((double)ntrace / (double)rows) : 1.0;
-        tot += al(nch * levels * 4.0);
         return tot;
+    };
+    auto plan_shadow = [&](const Caps& cp, double nch) -> double {
+        auto al = [&](double b) { return c->arena ? std::ceil(std::max(b, 1.0) / 256.0) * 256.0 : b; };
+        size_t mx = 0;
+        for (size_t v : cp.cap) mx = std::max(mx, v);
+        const double qcap = (double)mx * (double)nl1 + (double)c->qpad;
+        const double nb = (double)c->nbins, ng = std::ceil(nb / 1024.0);
+        return nlanes * (2.0 * al(qcap * 16.0) + 2.0 * al(nb * 4.0) + al(qcap * 4.0) + 2.0 * al(ng * 4.0)) + al(nch * levels * 4.0 * 2.0);
+    };
+    auto too_big = [&](const Caps& cp) {
+        size_t mx = 0;
+        for (size_t v : cp.cap) mx = std::max(mx, v);
+        return (double)mx * (double)nl1 + (double)c->qpad > (double)(((int64_t)1 << 30));
+    };
+    auto alloc_levels = [&](const Caps& cp, bool with_lit) -> int {
+        c->L.assign(levels, LevelDev{});
+        for (int k = 0; k < levels; k++) {
+            LevelDev& L = c->L[k];
+            const size_t cap = std::max<size_t>(cp.cap[k], 1);
+            if (cap > ((size_t)1 << 30)) return RTX_E_TOO_LARGE;
+            L.cap = (int)cap;
+            float** fl[] = {&L.ox, &L.oy, &L.oz, &L.dx, &L.dy, &L.dz, &L.t, &L.n_nx, &L.n_ny, &L.n_nz, &L.n_px, &L.n_py, &L.n_pz, &L.n_fres};
+            for (float** f : fl)
+                if ((rc = c->dalloc(f, cap))) return rc;
+            int** il[] = {&L.prim, &L.n_ray, &L.n_crefl, &L.n_crefr};
+            for (int** f : il)
+                if ((rc = c->dalloc(f, cap))) return rc;
+            if (k == 0) L.val = nullptr;  // level-0 colours are written straight into the float image
+            else if ((rc = c->dalloc(&L.val, cap * 3))) return rc;
+            if (with_lit && (rc = c->dalloc(&L.lit, cap * nl1))) return rc;
+        }
+        return RTX_OK;
     };
     uint64_t budget = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
     if (c->arena) budget = c->arena_cap - c->arena_off;
+    if ((rc = c->dalloc(&c->d_overflow, 1))) return rc;
+    HIPCHK(hipMemset(c->d_overflow, 0, sizeof(int)));
+
+    Caps caps;
     int64_t rows = ntrace > 0 ? ntrace : 1;
-    // the deepest level's shadow queue must stay indexable by int
-    auto too_big = [&](int64_t r) { return (double)r * W * std::pow(fan, levels - 1) * (double)nl1 + (double)c->qpad > (double)(((int64_t)1 << 30)); };
-    if (plan(rows) > (double)budget || too_big(rows)) {
-        // bisect the largest chunk that fits (plan is monotone in rows)
-        int64_t lo = 0, hi = rows;  // lo fits (0 rows: nothing), hi does not
-        while (hi - lo > 1) {
-            const int64_t mid = lo + (hi - lo) / 2;
-            if (plan(mid) > (double)budget || too_big(mid)) hi = mid; else lo = mid;
+    const bool calibrate = c->fanout >= 2 && levels >= 2 && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
+    if (!calibrate) {
+        // worst case = what exists (fan-out 1), or a mode that is not worth a calibration pass
+        auto fits = [&](int64_t r) { const Caps cp = worst_caps(r); return !(plan_levels(cp, true) + plan_shadow(cp, ntrace ? std::ceil((double)ntrace / (double)r) : 1.0) > (double)budget || too_big(cp)); };
+        if (!fits(rows)) {
+            int64_t lo = 0, hi = rows;  // lo fits (0 rows: nothing), hi does not; fits() is monotone
+            while (hi - lo > 1) {
+                const int64_t mid = lo + (hi - lo) / 2;
+                if (fits(mid)) lo = mid; else hi = mid;
+            }
+            rows = lo;
         }
-        rows = lo;
-    }
-    if (rows < 1) {
-        if (c->arena || too_big(1)) return RTX_E_TOO_LARGE;  // not even one row of queues fits
-        rows = 1;  // a workspace_bytes cap below one row is a hint, not a limit
+        if (rows < 1) {
+            if (c->arena || too_big(worst_caps(1))) return RTX_E_TOO_LARGE;  // not even one row of queues fits
+            rows = 1;  // a workspace_bytes cap below one row is a hint, not a limit
+        }
+        caps = worst_caps(rows);
+    } else {
+        // (a) calibration blocks: worst-case capacities for r_cal rows within a bounded scratch budget
+        const uint64_t cal_budget = std::min<uint64_t>(budget, (uint64_t)4 << 30);
+        int64_t r_cal = ntrace;
+        auto cal_fits = [&](int64_t r) { const Caps cp = worst_caps(r); return !(plan_levels(cp, false) > (double)cal_budget || too_big(cp)); };
+        if (!cal_fits(r_cal)) {
+            int64_t lo = 0, hi = r_cal;
+            while (hi - lo > 1) {
+                const int64_t mid = lo + (hi - lo) / 2;
+                if (cal_fits(mid)) lo = mid; else hi = mid;
+            }
+            r_cal = lo;
+        }
+        if (r_cal < 1) {
+            if (c->arena || too_big(worst_caps(1))) return RTX_E_TOO_LARGE;
+            r_cal = 1;
+        }
+        const int nblk = (int)((ntrace + r_cal - 1) / r_cal);
+        std::vector<int> blk((size_t)nblk * levels, 0);
+        {
+            const size_t mark_allocs = c->allocs.size(), mark_arena = c->arena_off;
+            int* d_blk = nullptr;
+            if ((rc = alloc_levels(worst_caps(r_cal), false))) return rc;
+            if ((rc = c->dalloc(&d_blk, blk.size()))) return rc;
+            c->chunk_rows = (int)r_cal;
+            if ((rc = calibrate_counts(c, d_blk))) return rc;
+            HIPCHK(hipMemcpy(blk.data(), d_blk, blk.size() * sizeof(int), hipMemcpyDeviceToHost));
+            // give the blocks back: hipFree in reverse order / rewind the arena
+            for (size_t i = c->allocs.size(); i > mark_allocs; i--) HIPCHK(hipFree(c->allocs[i - 1]));
+            c->allocs.resize(mark_allocs);
+            c->arena_off = mark_arena;
+            c->L.clear();
+        }
+        // (b) the largest chunk (a whole number m of calibration blocks) whose measured capacities fit the budget
+        auto caps_for = [&](int m) {
+            Caps cp; cp.cap.assign(levels, 0);
+            for (int b0 = 0; b0 < nblk; b0 += m)
+                for (int k = 0; k < levels; k++) {
+                    size_t sum = 0;
+                    for (int b = b0; b < std::min(nblk, b0 + m); b++) sum += (size_t)blk[(size_t)b * levels + k];
+                    cp.cap[k] = std::max(cp.cap[k], sum);
+                }
+            for (int k = 0; k < levels; k++) cp.cap[k] = (cp.cap[k] + 255) / 256 * 256;  // whole workgroups
+            return cp;
+        };
+        auto fits = [&](int m) { const Caps cp = caps_for(m); return !(plan_levels(cp, true) + plan_shadow(cp, std::ceil((double)nblk / (double)m)) > (double)budget || too_big(cp)); };
+        int m = nblk;
+        if (!fits(m)) {
+            int lo = 0, hi = m;  // more blocks per chunk never needs less memory
+            while (hi - lo > 1) {
+                const int mid = lo + (hi - lo) / 2;
+                if (fits(mid)) lo = mid; else hi = mid;
+            }
+            m = lo;
+        }
+        if (m < 1) {
+            if (c->arena) return RTX_E_TOO_LARGE;
+            m = 1;
+        }
+        rows = std::min<int64_t>((int64_t)m * r_cal, ntrace);
+        caps = caps_for(m);
+        c->calibrated = true;
     }
     c->chunk_rows = (int)rows;
-
-    c->L.resize(levels);
-    size_t cap = (size_t)c->chunk_rows * W;
-    for (int k = 0; k < levels; k++) {
-        LevelDev& L = c->L[k];
-        if (cap > ((size_t)1 << 30)) return RTX_E_TOO_LARGE;
-        L.cap = (int)cap;
-        float** fl[] = {&L.ox, &L.oy, &L.oz, &L.dx, &L.dy, &L.dz, &L.t, &L.n_nx, &L.n_ny, &L.n_nz, &L.n_px, &L.n_py, &L.n_pz, &L.n_fres};
-        for (float** f : fl)
-            if ((rc = c->dalloc(f, cap))) return rc;
-        int** il[] = {&L.prim, &L.n_ray, &L.n_crefl, &L.n_crefr};
-        for (int** f : il)
-            if ((rc = c->dalloc(f, cap))) return rc;
-        if (k == 0) L.val = nullptr;  // level-0 colours are written straight into the float image
-        else if ((rc = c->dalloc(&L.val, cap * 3))) return rc;
-        if ((rc = c->dalloc(&L.lit, cap * nl1))) return rc;
-        if (c->fanout >= 2 && k + 1 < levels) cap *= 2;
-    }
+    if ((rc = alloc_levels(caps, true))) return rc;
     {   // shadow-ray queues: the largest generation's hits x lights
-        size_t qcap = (size_t)c->L[levels - 1].cap * nl1 + c->qpad;
+        size_t mx = 0;
+        for (int k = 0; k < levels; k++) mx = std::max(mx, (size_t)c->L[k].cap);
+        size_t qcap = mx * nl1 + c->qpad;
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
         const size_t maxbins = (size_t)c->nbins;
         for (int i = 0; i <= nside; i++) {
@@ -439,7 +541,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->dalloc(&sl.braw, (maxbins + 1023) / 1024))) return rc;
         }
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
-        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels))) return rc;
+        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * 2))) return rc;
     }
     if (c->arena) return RTX_OK;  // arena mode creates no streams and no events
     HIPCHK(hipEventCreate(&c->ev0));
@@ -460,6 +562,44 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
 }
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline unsigned grid_for_isect(size_t cap);
+
+// Calibration pass (context_create_impl): closest hit + set-up of every generation, block of chunk_rows rows by block,
+// on the default stream; d_blk[block * levels + k] = rays of generation k in that block.  The levels hold worst-case
+// capacities here; no shadow rays, no shading.
+static int calibrate_counts(rtx_context* c, int* d_blk)
+{
+    const int W = c->width, levels = c->levels, ntrace = (int)c->trace_rows.size();
+    hipStream_t st = nullptr;
+    int* rays = c->d_cnt;
+    int* nodes = c->d_cnt + levels;
+    int blk = 0;
+    for (int ti0 = 0; ti0 < ntrace; ti0 += c->chunk_rows, blk++) {
+        const int nrows = std::min(c->chunk_rows, ntrace - ti0);
+        const size_t npix = (size_t)nrows * W;
+        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * 2 * levels, st));
+        LevelDev L0 = c->L[0];
+        L0.val = c->d_fimg + (size_t)ti0 * W * 3;
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
+        size_t live_cap = npix;
+        for (int k = 0; k < levels; k++) {
+            LevelDev Lk = (k == 0) ? L0 : c->L[k];
+            LevelDev Ln = (k + 1 < levels) ? c->L[k + 1] : Lk;
+            const int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
+            if (!spawn) break;  // the last generation spawns nothing: its count is already known
+            const unsigned g = grid_for(live_cap);
+            if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else if (live_cap < kPrefetchRays) hipLaunchKernelGGL((k_closest_f<true, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            else hipLaunchKernelGGL((k_closest_f<false, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, rays + k + 1, spawn, c->d_overflow);
+            live_cap = std::min(live_cap * 2, (size_t)c->L[k + 1].cap);
+        }
+        HIPCHK(hipMemcpyAsync(d_blk + (size_t)blk * levels, rays, sizeof(int) * levels, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return RTX_OK;
+}
 // intersection kernels: thin generations (<= kThinRays live rays) use 64 rays per workgroup
 static inline unsigned grid_for_isect(size_t cap) { return std::max(grid_for(cap), (unsigned)((std::min<size_t>(cap, kThinRays) + 63) / 64)); }
 
@@ -516,9 +656,9 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits
             // for a whole CU to drain
             if (k == 0) hipLaunchKernelGGL(k_setup<kSetupBlock>, dim3((unsigned)((live_cap + kSetupBlock - 1) / kSetupBlock)), dim3(kSetupBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
-                               spawn ? rays + k + 1 : rays + k, spawn);
+                               spawn ? rays + k + 1 : rays + k, spawn, c->d_overflow);
             else hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
-                               spawn ? rays + k + 1 : rays + k, spawn);
+                               spawn ? rays + k + 1 : rays + k, spawn, c->d_overflow);
             if (c->S.nl > 0 && (count || exact_only)) {
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
                 if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);
@@ -554,6 +694,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 if (!on_main) HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }
             if (c->fanout >= 2) live_cap *= 2;
+            if (k + 1 < levels) live_cap = std::min(live_cap, (size_t)c->L[k + 1].cap);  // calibrated capacities (fan-out 2)
         }
         for (int k = levels - 1; k >= 0; k--) {
             LevelDev Lk = (k == 0) ? L0 : c->L[k];
@@ -598,6 +739,11 @@ static int context_stats_impl(rtx_context* c, rtx_stats* s)
     s->tests_closest = (s->rays_primary + s->rays_secondary) * nprims;
     s->tests_shadow_max = s->rays_shadow * nprims;
     s->singular_matrices = c->singular;
+    {
+        int ov = 0;
+        HIPCHK(hipMemcpy(&ov, c->d_overflow, sizeof ov, hipMemcpyDeviceToHost));
+        s->queue_overflow = (uint64_t)(ov < 0 ? 0 : ov);
+    }
     s->chunks = c->nchunks;
     s->levels = c->levels;
     float ms = 0;

@@ -258,7 +258,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_closest(SceneDev S, LevelDev L, const int* nrays, unsigned long long* tests)
 {
     int i = blockIdx.x * kBlock + threadIdx.x;
-    bool live = i < *nrays;
+    bool live = i < min(*nrays, L.cap);
     if (!COUNT && !live) return;
     unsigned int cnt[4] = {0, 0, 0, 0};
     if (live) {

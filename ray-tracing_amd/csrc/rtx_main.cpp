@@ -19,6 +19,7 @@ int main(int argc, char** argv)
     p.max_depth = 4;     // raytracing.cpp:12
     p.device = -1;
     int ngpus = 1;
+    bool legacy = false;
     std::vector<const char*> pos;
     for (int i = 1; i < argc; i++) {
         auto val = [&](const char* name) -> const char* {
@@ -32,6 +33,9 @@ int main(int argc, char** argv)
         else if ((v = val("--max-depth"))) p.max_depth = std::atoi(v);
         else if ((v = val("--gpus"))) ngpus = std::atoi(v);
         else if ((v = val("--band-rows"))) p.band_rows = std::atoi(v);
+        else if (std::strcmp(argv[i], "--legacy-grammar") == 0) legacy = true;          // opt-in: rtx_scene_load_legacy
+        else if (std::strcmp(argv[i], "--trace-planes") == 0) p.flags |= RTX_F_TRACE_PLANES;   // opt-in extension
+        else if (std::strcmp(argv[i], "--moller-trumbore") == 0) p.flags |= RTX_F_TRI_MOLLER_TRUMBORE;  // opt-in, non-parity
         else pos.push_back(argv[i]);
     }
     if (pos.size() != 2) {  // :983-988
@@ -40,7 +44,7 @@ int main(int argc, char** argv)
         std::exit(0);
     }
     rtx_scene* scene = nullptr;
-    int rc = rtx_scene_load(pos[0], &scene);
+    int rc = legacy ? rtx_scene_load_legacy(pos[0], &scene) : rtx_scene_load(pos[0], &scene);
     if (rc) { std::fprintf(stderr, "rtx: cannot read %s: %s\n", pos[0], rtx_strerror(rc)); return 1; }
     std::vector<uint8_t> rgb((size_t)p.width * p.height * 3);
     rtx_stats st;

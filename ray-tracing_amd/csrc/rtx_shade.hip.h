@@ -10,10 +10,10 @@ namespace rtx {
 // ------------------------------------------------------------------------------------------------
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDev N, const int* nrays,
-                                                 int* nnodes, int* nnext, int spawn)
+                                                 int* nnodes, int* nnext, int spawn, int* overflow)
 {
     int i = blockIdx.x * BLOCK + threadIdx.x;
-    bool live = i < *nrays;
+    bool live = i < min(*nrays, L.cap);
     int pw = live ? L.prim[i] : -1;
     bool hit = pw >= 0;
     if (live && !hit) {  // :436-438: background, no ambient
@@ -114,6 +114,10 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         const int base = sh_alloc[2 * nw];
         if (want_refl) crefl = base + off1 + p1;
         if (want_refr) crefr = base + tot1 + off2 + p2;
+        // never past the next level's capacity (measured at creation, rtx_device.hip: cannot happen for the frame the
+        // context was calibrated on): the child is dropped and counted, its colour term is then simply missing
+        if (want_refl && crefl >= N.cap) { want_refl = false; crefl = -1; atomicAdd(overflow, 1); }
+        if (want_refr && crefr >= N.cap) { want_refr = false; crefr = -1; atomicAdd(overflow, 1); }
     }
     if (hit) { L.n_crefl[node] = crefl; L.n_crefr[node] = crefr; }
     if (want_refl) {  // :464-468

@@ -99,7 +99,7 @@ class Stats(C.Structure):
                 ("packet_stats", C.c_uint64 * 8),
                 ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32),
                 ("ms_closest_lanes", C.c_float), ("launches_closest_lanes", C.c_int32),
-                ("exec_counts", (C.c_uint64 * RTX_EXEC_KINDS) * 3)]
+                ("exec_counts", (C.c_uint64 * RTX_EXEC_KINDS) * 3), ("queue_overflow", C.c_uint64)]
 
     def exec_dict(self):
         """{kernel: {kind: count}} of the RTX_F_COUNT_EXEC counters."""
@@ -134,6 +134,7 @@ SYMBOLS = {
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
+    "rtx_scene_load_legacy": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
     "rtx_write_ppm": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
 }
@@ -170,9 +171,10 @@ def device_count():
 class Scene:
     """A scene parsed by the kept C++ reader (rtx_scene_load)."""
 
-    def __init__(self, path):
+    def __init__(self, path, legacy=False):
         self._p = C.POINTER(SceneView)()
-        _check(lib().rtx_scene_load(os.fsencode(path), C.byref(self._p)), f"rtx_scene_load({path})")
+        fn = lib().rtx_scene_load_legacy if legacy else lib().rtx_scene_load
+        _check(fn(os.fsencode(path), C.byref(self._p)), f"rtx_scene_load({path})")
         self.path = path
 
     @property
@@ -199,8 +201,9 @@ class Scene:
             pass
 
 
-def load_scene(path):
-    return Scene(path)
+def load_scene(path, legacy=False):
+    """legacy=True: the opt-in loader for the older grammars of the bundled scenes (rtx_scene_load_legacy)."""
+    return Scene(path, legacy)
 
 
 def band_rows(height, nranks, rank, band):

@@ -76,3 +76,25 @@ def test_moller_trumbore_is_a_non_parity_mode(rt, gpu, tmp_path):
     differ = float((ref != mt).any(axis=2).mean())
     print("Moller-Trumbore vs the reference's area test, C4 at %dx%d: %.3f %% of pixels differ (NON-PARITY mode)" % (W, H, differ * 100))
     assert 0.0 < differ < 0.10
+
+
+@pytest.mark.parametrize("name", ["inp.txt", "inp-refl.txt", "inpaffine.txt", "inp1.txt", "inp01.txt"])
+def test_legacy_grammar_scenes_match_oracle(rt, oracle, gpu, name):
+    """The bundled scenes as their authors wrote them (opt-in rtx_scene_load_legacy): spheres, the affine sphere of
+    inpaffine.txt, the triangle room, the cuboid, the polygon, reflection and refraction all really exercised, GPU
+    against the oracle on the same records; inp1.txt also with its six planes traced (RTX_F_TRACE_PLANES)."""
+    from conftest import GOLDEN
+    sc = rt.load_scene(os.path.join(GOLDEN, "bundled", name), legacy=True)
+    assert sc.view.nspheres >= 1 and sc.view.nlights == 1
+    W, H = 160, 120
+    for flags, oflags in ((0, 0),) + (((rt.host.F_TRACE_PLANES, oracle.TRACE_PLANES),) if sc.view.nplanes else ()):
+        g, st = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=flags))
+        with oracle.flags(oflags):
+            c, cnt = oracle.render_f32(sc, W, H, 4)
+            rc, _ = oracle.render_rgb8(sc, W, H, 4)
+        assert st.rays_primary + st.rays_secondary == cnt.trace_calls and st.rays_shadow == cnt.shadow_rays and st.hits == cnt.hits
+        assert st.hits > 500
+        same = raw_equal_mask(g, c)
+        assert same.mean() >= 0.999, (name, int((~same).sum()))
+        rg, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4, flags=flags))
+        assert_rgb8_parity(rg, rc, name + " (legacy grammar)")

@@ -80,6 +80,9 @@ def test_culling_is_exact_on_4k_frame(rt, gpu, c4_scene):
     rb, sb = rt.render_rgb8(c4_scene, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
     assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
     assert np.array_equal(ra, rb), "%d bytes differ" % int((ra != rb).sum())
+    # some primitives both reflect and refract (fan-out 2): the queues are sized by the calibration pass, not by 2^k --
+    # the whole 4K frame is ONE chunk and no ray was dropped; the exact-only context keeps the worst case and chunks
+    assert sa.chunks == 1 and sa.queue_overflow == 0 and sb.queue_overflow == 0 and sb.chunks >= 1
 
 
 def test_culling_is_exact_across_segments(rt, gpu, tmp_path):

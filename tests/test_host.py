@@ -111,3 +111,43 @@ def test_bench_launcher_honours_gpus():
     assert bench.launch_plan(0, {}, [])[0] == "error"
     a = bench.parse_args(["--gpus", "2", "--workload", "c5"])
     assert a.gpus == 2 and a.workload == "c5" and a.steps == 5
+
+
+def test_legacy_grammar_loader_reads_the_bundled_scenes_as_written(rt):
+    """rtx_scene_load_legacy (opt-in): the older line-per-record grammars documented by the bundled
+    files' own comment lines.  Record counts and a few fields of every bundled scene; the default loader is unchanged
+    (test_bundled_scenes_parse_as_the_head_grammar_does above)."""
+    b = os.path.join(GOLDEN, "bundled")
+    want = {  # spheres, triangles, planes, lights, polygons
+        "inp.txt": (5, 2, 0, 1, 0), "inp-refl.txt": (1, 3, 0, 1, 0), "inpaffine.txt": (5, 5, 0, 1, 0),
+        "inp1.txt": (9, 14 + 12, 6, 1, 0), "inp01.txt": (7, 12, 0, 1, 1)}
+    for name, counts in want.items():
+        sc = rt.load_scene(os.path.join(b, name), legacy=True); v = sc.view   # (the view lives as long as sc does)
+        assert (v.nspheres, v.ntriangles, v.nplanes, v.nlights, v.npolygons) == counts, name
+        assert (v.camera.x, v.camera.y, v.camera.z) == (0.0, 0.0, -1.0) and (v.up.x, v.up.y, v.up.z) == (0.0, 1.0, 0.0)
+    sc = rt.load_scene(os.path.join(b, "inpaffine.txt"), legacy=True); v = sc.view
+    s = v.spheres[0]   # sphere 2 -2 -30 4  1 0 0  1.0 0.0 1.0  1  3 0 0 0 1 0 0 0 1 0 0 0
+    assert (s.center.x, s.center.y, s.center.z, s.radius) == (2.0, -2.0, -30.0, 4.0)
+    assert (s.reflectivity, s.transparency, s.refractive_index, s.istransformed) == (1.0, 0.0, 1.0, 1)
+    assert (s.mat.a.x, s.mat.b.y, s.mat.c.z, s.mat.d.x) == (3.0, 1.0, 1.0, 0.0)
+    assert (s.diffcolor.x, s.diffcolor.y, s.diffcolor.z) == (s.color.x, s.color.y, s.color.z) == (1.0, 0.0, 0.0)
+    assert v.spheres[1].istransformed == 0 and v.spheres[1].reflectivity == 0.5
+    t = v.triangles[0]  # ... 0.80 0.60 0.70  1.5 0.0 0.0
+    assert (t.color.x, t.reflectivity, t.transparency, t.refractive_index) == (np.float32(0.8), 1.5, 0.0, 0.0)
+    l = v.lights[0]
+    assert (l.point.x, l.point.y, l.point.z, l.color.x) == (0.0, 10.0, -30.0, np.float32(0.33))
+    # inp.txt (the oldest grammar): colour only, everything else defaulted
+    sc = rt.load_scene(os.path.join(b, "inp.txt"), legacy=True); v = sc.view
+    s = v.spheres[0]
+    assert (s.reflectivity, s.transparency, s.refractive_index, s.istransformed, s.specexpo) == (0.0, 0.0, 1.0, 0, 20.0)
+    # inp1.txt: plane 2 0 0 200  1 1 0  0.4 0 1.5 (normal, d, colour, material), the cuboid as 12 triangles
+    sc = rt.load_scene(os.path.join(b, "inp1.txt"), legacy=True); v = sc.view
+    p = v.planes[0]
+    assert (p.normal.x, p.d, p.color.z, p.reflectivity, p.refractive_index) == (2.0, 200.0, 0.0, np.float32(0.4), 1.5)
+    xs = sorted({(tr.u.x, tr.u.y, tr.u.z) for tr in v.triangles[12:24]} | {(tr.w.x, tr.w.y, tr.w.z) for tr in v.triangles[12:24]}
+                | {(tr.v.x, tr.v.y, tr.v.z) for tr in v.triangles[12:24]})
+    assert len(xs) == 8 and xs[0] == (0.0, -10.0, -10.0) and xs[-1] == (10.0, 0.0, 0.0)
+    # inp01.txt: polygon 4 ... with parseinput's normal / centroid rules
+    sc = rt.load_scene(os.path.join(b, "inp01.txt"), legacy=True); v = sc.view
+    g = v.polygons[0]
+    assert g.numvertices == 4 and (g.centerPoint.x, g.centerPoint.y, g.centerPoint.z) == (0.0, 25.0, -40.0) and abs(g.normal.z) == 1.0

@@ -24,12 +24,12 @@ def _same(rt, sc, p):
 
 def test_noalloc_matches_render_rgb8_twice_second_smaller(rt, gpu, tmp_path):
     # first call: 2,000 primitives (affine spheres with their (light, cell) table, reflective and refractive, so
-    # fan-out 2 queues), 640x360, depth 4: several row chunks of the 64 MiB block
+    # fan-out 2 queues, so the capacities come from the calibration pass), 960x540, depth 4: several row chunks of the 64 MiB block
     big = tmp_path / "big.txt"
     rt.scenegen.write_scene(str(big), 1000, 1000, rt.scenegen.lights_c4(), seed=21, frac_affine=0.3,
                             frac_reflective=0.5, frac_refractive=0.2)
-    s1 = _same(rt, rt.load_scene(str(big)), rt.Params.make(640, 360, 3))
-    assert s1.chunks > 1
+    s1 = _same(rt, rt.load_scene(str(big)), rt.Params.make(960, 540, 3))
+    assert s1.chunks > 1 and s1.queue_overflow == 0
     # second call, smaller input in every respect: fewer primitives, fewer lights, smaller frame
     s2 = _same(rt, rt.load_scene(os.path.join(SCENES, "probe.txt")), rt.Params.make(96, 64, 4))
     assert s2.chunks == 1
