@@ -191,7 +191,8 @@ enum {
     RTX_E_HIP         = -3,
     RTX_E_OOM         = -4,
     RTX_E_IO          = -5,
-    RTX_E_TOO_LARGE   = -6
+    RTX_E_TOO_LARGE   = -6,
+    RTX_E_RCCL        = -7
 };
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -205,8 +206,10 @@ const char* rtx_last_hip_error(void);
 /* ---- one-shot drop-in: replaces raytracing.cpp:725-783 --------------------------------------
  * Renders the rows `params` selects (all of them for nranks <= 1) with 3x3 antialiasing and
  * the reference's 8-bit quantisation (:792-794) into rgb_out[rows * width * 3].  With
- * params->nranks <= 1 and ngpus > 1 the frame is split over the first `ngpus` devices of this
- * process (one host thread each) and assembled in rgb_out. */
+ * params->nranks <= 1 and ngpus > 1 the frame is split into bands of params->band_rows (default 16) rows round-robin
+ * over the first `ngpus` devices of this process, one context per device; the 8-bit bands are gathered into device 0
+ * with RCCL (grouped ncclSend / ncclRecv over xGMI; librccl.so is loaded on first use, RTX_E_RCCL if that or a
+ * collective fails), copied to the host once and put in place in rgb_out.  ngpus beyond the visible devices is clamped. */
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
                     uint8_t* rgb_out, rtx_stats* stats_or_null);
 

@@ -25,10 +25,13 @@
 // exact-only closest-hit kernel), rtx_closest.hip.h, rtx_shadow.hip.h and rtx_shade.hip.h (set-up,
 // unwind, antialias); this file holds the resident context and the C-ABI entry points.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded with dlopen on first multi-GPU use
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -784,48 +787,195 @@ static int render_one(const rtx_scene* scene, const rtx_params* params, uint8_t*
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// In-process multi-GPU (rtx_render_rgb8 with ngpus > 1; the CLI's --gpus=N): scanline bands round-robin over the
+// devices, ONE context per device, every band rendered straight into the buffer it is sent from, the 8-bit bands
+// gathered into device 0 with RCCL (grouped ncclSend / ncclRecv: each peer has its own xGMI link into device 0, so
+// the fan-in is point to point, not a ring), one device-to-host copy of the gathered bands, rows put in place.
+// RCCL is loaded on first use (dlopen: the library does not depend on it at load time, and a process that already
+// holds an RCCL -- PyTorch's -- shares it); failing that: RTX_E_RCCL.
+// RTX_MULTI_ON_ONE_DEVICE=1 (test aid for one-GPU machines): the ranks all run on device 0 and the exchange is
+// device-to-device copies instead of RCCL (which refuses two ranks on one device); everything else is the same code.
+// ------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+static Rccl& rccl()
+{
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            R.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (R.h) break;
+        }
+        if (!R.h) return;
+        R.CommInitAll = (decltype(R.CommInitAll))dlsym(R.h, "ncclCommInitAll");
+        R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+        R.GroupStart = (decltype(R.GroupStart))dlsym(R.h, "ncclGroupStart");
+        R.GroupEnd = (decltype(R.GroupEnd))dlsym(R.h, "ncclGroupEnd");
+        R.Send = (decltype(R.Send))dlsym(R.h, "ncclSend");
+        R.Recv = (decltype(R.Recv))dlsym(R.h, "ncclRecv");
+        R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+        R.ok = R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.GetErrorString;
+    });
+    return R;
+}
+
+#define NCCLCHK(expr)                                                                         \
+    do {                                                                                      \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            g_last_hip_error = std::string(#expr) + ": " + rccl().GetErrorString(r_);         \
+            rc = RTX_E_RCCL;                                                                  \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+#define HIPCHK_GOTO(expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_last_hip_error = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            rc = (e_ == hipErrorOutOfMemory) ? RTX_E_OOM : RTX_E_HIP;                         \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+
 static int render_multi(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
 {
-    // In-process multi-GPU: one host thread per device, interleaved bands, each device copies
-    // its own rows to the host over its own PCIe link; rows are placed in the caller's frame.
-    int ndev = rtx_device_count();
+    const int ndev = rtx_device_count();
     if (ndev <= 0) return RTX_E_NO_DEVICE;
-    if (ngpus > ndev) ngpus = ndev;
-    std::vector<int> rcs(ngpus, 0);
-    std::vector<rtx_stats> sts(ngpus);
-    std::vector<std::thread> th;
+    const char* one = std::getenv("RTX_MULTI_ON_ONE_DEVICE");
+    const bool on_one = one && one[0] == '1';
+    if (!on_one && ngpus > ndev) ngpus = ndev;
+    if (ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
+    if (ngpus > 64) ngpus = 64;
+    const int G = ngpus;
     const size_t rowb = (size_t)params->width * 3;
-    for (int g = 0; g < ngpus; g++)
-        th.emplace_back([&, g]() {
-            rtx_params p = *params;
-            p.nranks = ngpus; p.rank = g; p.device = g;
-            if (p.band_rows <= 0) p.band_rows = 16;
-            int n = rtx_band_rows(p.height, p.nranks, p.rank, p.band_rows, nullptr, 0);
-            if (n <= 0) { rcs[g] = n < 0 ? n : 0; std::memset(&sts[g], 0, sizeof(rtx_stats)); return; }
-            std::vector<int32_t> rows(n);
-            rtx_band_rows(p.height, p.nranks, p.rank, p.band_rows, rows.data(), n);
-            std::vector<uint8_t> tmp((size_t)n * rowb);
-            rcs[g] = render_one(scene, &p, tmp.data(), nullptr, &sts[g]);
-            if (rcs[g]) return;
-            for (int r = 0; r < n; r++) std::memcpy(out + (size_t)rows[r] * rowb, tmp.data() + (size_t)r * rowb, rowb);
-        });
-    for (auto& t : th) t.join();
-    for (int g = 0; g < ngpus; g++)
-        if (rcs[g]) return rcs[g];
+    const int band = params->band_rows > 0 ? params->band_rows : 16;
+
+    int rc = RTX_OK;
+    std::vector<rtx_context*> ctx(G, nullptr);
+    std::vector<hipStream_t> stream(G, nullptr);
+    std::vector<int> dev(G), rcs(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<std::vector<int32_t>> rows(G);
+    std::vector<ncclComm_t> comms(G, nullptr);
+    unsigned char* d_gather = nullptr;   // on device 0: G slots of `slot` bytes, slot g = rank g's packed rows
+    std::vector<uint8_t> host;
+    size_t slot = 0;
+    bool have_comms = false;
+    for (int g = 0; g < G; g++) {
+        dev[g] = on_one ? 0 : g;
+        int n = rtx_band_rows(params->height, G, g, band, nullptr, 0);
+        if (n < 0) return n;
+        rows[g].resize(n);
+        if (n) rtx_band_rows(params->height, G, g, band, rows[g].data(), n);
+        slot = std::max(slot, (size_t)n * rowb);
+    }
+    slot = (slot + 255) & ~(size_t)255;
+
+    {   // one context per device, created concurrently (scene packing and upload are per device)
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; g++)
+            th.emplace_back([&, g]() {
+                try {
+                    if (rows[g].empty()) return;
+                    rtx_params p = *params;
+                    p.nranks = G; p.rank = g; p.device = dev[g]; p.band_rows = band;
+                    rcs[g] = rtx_context_create(scene, &p, &ctx[g]);
+                    if (!rcs[g] && hipStreamCreateWithFlags(&stream[g], hipStreamNonBlocking) != hipSuccess) rcs[g] = RTX_E_HIP;
+                } catch (const std::bad_alloc&) { rcs[g] = RTX_E_OOM; }
+                catch (...) { rcs[g] = RTX_E_HIP; }
+                if (rcs[g]) errs[g] = g_last_hip_error;  // the worker's own thread-local text
+            });
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) { rc = rcs[g]; g_last_hip_error = "device " + std::to_string(dev[g]) + ": " + errs[g]; goto done; }
+
+    HIPCHK_GOTO(hipSetDevice(dev[0]));
+    HIPCHK_GOTO(hipMalloc((void**)&d_gather, slot * (size_t)G));
+    if (!stream[0]) HIPCHK_GOTO(hipStreamCreateWithFlags(&stream[0], hipStreamNonBlocking));
+    if (!on_one) {
+        if (!rccl().ok) { g_last_hip_error = "librccl.so could not be loaded (dlopen)"; rc = RTX_E_RCCL; goto done; }
+        NCCLCHK(rccl().CommInitAll(comms.data(), G, dev.data()));
+        have_comms = true;
+    }
+    // every rank renders into the buffer its band is sent from: rank 0 straight into its slot of the gather buffer
+    for (int g = 0; g < G; g++) {
+        if (!ctx[g]) continue;
+        int r = rtx_context_render(ctx[g], stream[g], g == 0 ? d_gather : nullptr);
+        if (r) { rc = r; goto done; }
+    }
+    if (!on_one) {
+        NCCLCHK(rccl().GroupStart());
+        for (int g = 1; g < G; g++) {
+            if (!ctx[g]) continue;
+            const size_t bytes = rows[g].size() * rowb;
+            HIPCHK_GOTO(hipSetDevice(dev[g]));
+            NCCLCHK(rccl().Send(ctx[g]->d_rgb8, bytes, ncclUint8, 0, comms[g], stream[g]));
+            HIPCHK_GOTO(hipSetDevice(dev[0]));
+            NCCLCHK(rccl().Recv(d_gather + (size_t)g * slot, bytes, ncclUint8, g, comms[0], stream[0]));
+        }
+        NCCLCHK(rccl().GroupEnd());
+    } else {
+        for (int g = 1; g < G; g++) {
+            if (!ctx[g]) continue;
+            HIPCHK_GOTO(hipMemcpyAsync(d_gather + (size_t)g * slot, ctx[g]->d_rgb8, rows[g].size() * rowb, hipMemcpyDeviceToDevice, stream[g]));
+        }
+    }
+    for (int g = G - 1; g >= 0; g--) {
+        if (!stream[g]) continue;
+        HIPCHK_GOTO(hipSetDevice(dev[g]));
+        HIPCHK_GOTO(hipStreamSynchronize(stream[g]));
+    }
+    // ONE device-to-host copy of the gathered bands, then the rows go to their places in the caller's frame
+    host.resize(slot * (size_t)G);
+    HIPCHK_GOTO(hipSetDevice(dev[0]));
+    HIPCHK_GOTO(hipMemcpy(host.data(), d_gather, host.size(), hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; g++)
+        for (size_t r = 0; r < rows[g].size(); r++)
+            std::memcpy(out + (size_t)rows[g][r] * rowb, host.data() + (size_t)g * slot + r * rowb, rowb);
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        for (int g = 0; g < ngpus; g++) {
-            const rtx_stats& s = sts[g];
+        for (int g = 0; g < G; g++) {
+            if (!ctx[g]) continue;
+            rtx_stats s;
+            int r = rtx_context_stats(ctx[g], &s);
+            if (r) { rc = r; goto done; }
             stats->rays_primary += s.rays_primary; stats->rays_secondary += s.rays_secondary;
             stats->rays_shadow += s.rays_shadow; stats->hits += s.hits;
             for (int k = 0; k < RTX_MAX_LEVELS; k++) stats->rays_level[k] += s.rays_level[k];
             stats->tests_closest += s.tests_closest; stats->tests_shadow_max += s.tests_shadow_max;
-            stats->singular_matrices = s.singular_matrices;
+            stats->singular_matrices = s.singular_matrices; stats->queue_overflow += s.queue_overflow;
             stats->chunks += s.chunks; stats->levels = std::max(stats->levels, s.levels);
             stats->ms_total = std::max(stats->ms_total, s.ms_total);
         }
     }
-    return RTX_OK;
+done:
+    {
+        const std::string keep = g_last_hip_error;
+        if (have_comms)
+            for (int g = 0; g < G; g++)
+                if (comms[g]) (void)rccl().CommDestroy(comms[g]);
+        for (int g = 0; g < G; g++) {
+            if (ctx[g]) rtx_context_destroy(ctx[g]);
+            if (stream[g]) { (void)hipSetDevice(dev[g]); (void)hipStreamDestroy(stream[g]); }
+        }
+        if (d_gather) { (void)hipSetDevice(dev[0]); (void)hipFree(d_gather); }
+        if (rc) g_last_hip_error = keep;
+    }
+    return rc;
 }
 
 // No entry point lets a C++ exception cross the C-ABI (include/rtx.h): host-side allocations can throw.

@@ -108,6 +108,7 @@ const char* rtx_strerror(int code)
         case RTX_E_OOM: return "out of memory";
         case RTX_E_IO: return "file I/O error";
         case RTX_E_TOO_LARGE: return "request exceeds a fixed limit";
+        case RTX_E_RCCL: return "RCCL error (see rtx_last_hip_error)";
         default: return "unknown error";
     }
 }

@@ -94,6 +94,30 @@ def test_render_into_a_device_buffer(rt, gpu):
         hip.hipFree(buf)
 
 
+@pytest.mark.parametrize("ngpus,band", [(2, 0), (3, 7)])
+def test_in_process_multi_gpu_equals_one_device(rt, gpu, ngpus, band):
+    """rtx_render_rgb8(..., ngpus > 1), the CLI's --gpus: one context per device, bands rendered into their send buffers,
+    gathered into device 0 (RCCL ncclSend / ncclRecv where >= ngpus devices are visible; on a one-GPU box the same code
+    with every rank on device 0 and device-to-device copies in place of RCCL, RTX_MULTI_ON_ONE_DEVICE=1), ONE copy to
+    the host: byte-identical to the one-device frame, ray totals = the ranks' halo-inclusive sums."""
+    sc = rt.load_scene(os.path.join(SCENES, "room.txt"))
+    W, H = 200, 150
+    want, s1 = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
+    real = gpu >= ngpus
+    if not real:
+        os.environ["RTX_MULTI_ON_ONE_DEVICE"] = "1"
+    try:
+        got, sn = rt.render_rgb8(sc, rt.Params.make(W, H, 4, band_rows=band), ngpus=ngpus)
+    finally:
+        os.environ.pop("RTX_MULTI_ON_ONE_DEVICE", None)
+    print("multi-GPU path:", "RCCL over %d devices" % ngpus if real else "%d ranks on device 0 (no RCCL)" % ngpus)
+    assert np.array_equal(got, want)
+    assert sn.rays_primary >= s1.rays_primary and sn.queue_overflow == 0   # halo rows are traced by two ranks
+    # ngpus beyond the devices present is clamped, not an error
+    got2, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4), ngpus=gpu + 5)
+    assert np.array_equal(got2, want)
+
+
 def test_cli_is_a_drop_in(rt, oracle, gpu, tmp_path):
     """`raytrace_amd <scene> <out.ppm>` (raytracing.cpp:981-995): same arguments, same bytes as the
     reference's 640x480 output (md5 fixtures of the real reference) on ALL FIVE bundled scenes
@@ -120,6 +144,35 @@ def test_cli_is_a_drop_in(rt, oracle, gpu, tmp_path):
     # wrong argument count: usage text, exit status 0 (rt.cpp:983-988)
     p = subprocess.run([exe, "only-one-arg"], capture_output=True)
     assert p.returncode == 0 and b"Please follow the specifications!" in p.stdout
+
+
+def test_reference_with_the_binding_compiled_in(rt, gpu, tmp_path):
+    """oracle/_ref/rt_bound = the reference's own main, parseinput, globals and structs with render2Dantialiasing's
+    body replaced by INTEGRATION.md section 2's binding (oracle/Makefile `bound`; static_asserts on every field offset
+    of the reference's records against include/rtx.h at compile time).  Its 640x480 output: the real reference's md5 on
+    the five bundled scenes, and byte for byte what this repository's own loader + CLI write on the HEAD-grammar scenes
+    (&spheres[0] of the reference's std::vector round-trips)."""
+    import glob
+    import hashlib
+    import json
+    exe = os.path.join(ROOT, "oracle", "_ref", "rt_bound")
+    assert os.path.exists(exe), "oracle/_ref/rt_bound missing: make -C oracle bound (build container only)"
+    cli = os.path.join(ROOT, "ray-tracing_amd", "raytrace_amd")
+    idx = json.load(open(os.path.join(GOLDEN, "index.json")))
+    want = {r["scene"]: r["ppm_md5"] for r in idx["runs"] if not r["ppm"] and r["width"] == 640}
+    scenes = [("bundled/" + os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(GOLDEN, "bundled", "*.txt")))]
+    scenes += [("scenes/" + os.path.basename(p), p) for p in sorted(glob.glob(os.path.join(SCENES, "*.txt")))]
+    assert len(scenes) >= 12
+    for rel, path in scenes:
+        a, b = tmp_path / "bound.ppm", tmp_path / "cli.ppm"
+        subprocess.run([exe, path, str(a)], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([cli, path, str(b)], check=True, stdout=subprocess.DEVNULL)
+        da = a.read_bytes()
+        assert da == b.read_bytes(), rel
+        same = hashlib.md5(da).hexdigest() == want[rel]
+        print(rel, "md5 == the real reference's:", same)
+        if rel.startswith("bundled/"):
+            assert same, rel
 
 
 def test_full_size_tierb_md5(rt, oracle, gpu):
