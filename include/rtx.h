@@ -130,6 +130,8 @@ typedef struct rtx_params {
                                    the reference's area test with its absolute 0.01 tolerance (:329-366).  Edge
                                    pixels differ from the reference's; the mismatch rate is reported by the tests, never
                                    counted as parity. */
+#define RTX_F_WORST_CASE_QUEUES 512u /* size every generation's ray queue for fanout^k rays per pixel instead of the counts a
+                                   calibration pass measures at creation (A/B aid; same image) */
 #define RTX_F_COUNT_EXEC   64u  /* run the counting instantiations of the PRODUCTION intersection kernels (slower: atomics):
                                    what they actually evaluate, by kind -> rtx_stats.exec_counts.  Same image. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):

@@ -921,8 +921,11 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 constexpr int kSplitClosest = 1 << 17;
 constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
+#ifndef RTX_WAVES_LANES
+#define RTX_WAVES_LANES 5
+#endif
 template <bool EX = false>
-__global__ __launch_bounds__(kBlock) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_LANES))) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
 {
     __shared__ PoolLds pool[kBlock / 64];
     const int n = min(*nrays, L.cap);

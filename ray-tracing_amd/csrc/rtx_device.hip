@@ -444,7 +444,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
 
     Caps caps;
     int64_t rows = ntrace > 0 ? ntrace : 1;
-    const bool calibrate = c->fanout >= 2 && levels >= 2 && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
+    // (fan-out 1 scenes are calibrated too: their bound is the pixel count at EVERY level while the deep generations hold a
+    // few per cent of that, and every launch covers a level's capacity: 5.77 -> 5.59 ms per 4K frame, 2 GB less memory)
+    const bool calibrate = c->fanout >= 1 && levels >= 2 && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS | RTX_F_WORST_CASE_QUEUES));
     if (!calibrate) {
         // worst case = what exists (fan-out 1), or a mode that is not worth a calibration pass
         auto fits = [&](int64_t r) { const Caps cp = worst_caps(r); return !(plan_levels(cp, true) + plan_shadow(cp, ntrace ? std::ceil((double)ntrace / (double)r) : 1.0) > (double)budget || too_big(cp)); };
@@ -465,7 +467,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         // (a) calibration blocks: worst-case capacities for r_cal rows within a bounded scratch budget
         const uint64_t cal_budget = std::min<uint64_t>(budget, (uint64_t)4 << 30);
         int64_t r_cal = ntrace;
-        auto cal_fits = [&](int64_t r) { const Caps cp = worst_caps(r); return !(plan_levels(cp, false) > (double)cal_budget || too_big(cp)); };
+        // a block also fits the final layout at its worst case, so one block per chunk (m = 1 below) always fits the budget
+        auto cal_fits = [&](int64_t r) {
+            const Caps cp = worst_caps(r);
+            return !(plan_levels(cp, false) > (double)cal_budget || too_big(cp) ||
+                     plan_levels(cp, true) + plan_shadow(cp, std::ceil((double)ntrace / (double)r)) > (double)budget);
+        };
         if (!cal_fits(r_cal)) {
             int64_t lo = 0, hi = r_cal;
             while (hi - lo > 1) {
@@ -691,8 +698,20 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split4)) * kSplit));
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split8)) * 2 * kSplit));
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], ss)); }
-                if (exec) hipLaunchKernelGGL(k_shadow_pass<true>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
-                else hipLaunchKernelGGL(k_shadow_pass<false>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                // scenes with affine spheres: a generation that can fill the chip runs the traversal of the plain primitives
+                // and the affine spheres as two kernels (registers: 65 / 93 VGPRs instead of 104 together), a thin one as one
+                const bool fused = c->S.naff > 0 && live_cap * (size_t)c->S.nl <= (size_t)c->split4;
+                if (fused) {
+                    if (exec) hipLaunchKernelGGL((k_shadow_affine<true, true>), dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                    else hipLaunchKernelGGL((k_shadow_affine<false, true>), dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                } else {
+                    if (exec) hipLaunchKernelGGL(k_shadow_pass<true>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                    else hipLaunchKernelGGL(k_shadow_pass<false>, dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                    if (c->S.naff > 0) {
+                        if (exec) hipLaunchKernelGGL((k_shadow_affine<true, false>), dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                        else hipLaunchKernelGGL((k_shadow_affine<false, false>), dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8);
+                    }
+                }
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used + 1], ss)); kev_used += 2; c->kev_kind.push_back(1); }
                 if (!on_main) HIPCHK(hipEventRecord(c->ev_pass[k], ss));
             }

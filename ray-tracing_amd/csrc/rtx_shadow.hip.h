@@ -319,6 +319,14 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: every affine sphere is tested
 
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
+// PHASE 0: plain spheres and triangles (the shadow cluster hierarchy).  PHASE 1: affine spheres (strip test), for the
+// rays PHASE 0 left lit -- a kernel of its own, launched behind PHASE 0 on the same stream when the scene has affine
+// spheres: the strip test's registers (16-float records, an orthonormal frame per sphere) on top of the traversal's
+// held the one-kernel form at 104 VGPRs = 4 waves per SIMD, and this kernel is bound by latency, not by issue
+// (forcing 6 waves with spills: 5.59 -> 5.20 ms per 4K frame); apart, the traversal takes 65 (7 waves): 5.00 ms.
+// PHASE 2: both in one kernel, the old form -- for thin generations, whose few waves do not fill the SIMDs anyway and
+// which would only pay the second launch.
+template <int PHASE>
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
                                                    unsigned char* lit, const int lit_cap, const int part, const int parts,
                                                    unsigned short* alist, Exec* ex)
@@ -335,10 +343,16 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     F3 nld = normalized(ld);
     const bool abn = ray_abnormal(o, ld, nld, S.guard);
     const bool use = live && !abn;
-    F3 fo = use ? o : f3(1e18f, 0.0f, 0.0f);
+    // (the per-ray filter reads the origin itself: lanes that are done, outside the block being traced or abnormal are
+    // masked by `done` / never reach a packet block, so no parked copy of the origin is kept -- registers are what bounds
+    // this kernel's occupancy)
     F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
     bool done = !live;
-    if (live && part == 0) ex_add(ex, EX_RAYS);
+    if (PHASE == 1) {
+        if (live && lit[id] == 0) done = true;   // blocked by a plain primitive already (PHASE 0, same stream)
+        if (__all(done)) return;                  // wave-uniform
+    }
+    if (PHASE != 1 && live && part == 0) ex_add(ex, EX_RAYS);
     int pk_batches = 0, pk_surv = 0, pk_blocks = 0, pk_ok = 0, pk_aff = 0;
     auto bcast4 = [](float4 v, int u) {
         float4 r;
@@ -358,7 +372,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     // Any ray the table does not cover (too far from its light), or a list that does not fit: every affine sphere.
     int nlist = S.naff;
     bool listed = false;
-    if (S.aff_cells != nullptr && S.naff > 0) {
+    if (PHASE != 0 && S.aff_cells != nullptr && S.naff > 0) {
         bool covered = true;
         int key = -1;
         if (live && !abn) {  // abnormal rays take the transposed scan over everything below
@@ -396,7 +410,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             }
         }
     }
-    unsigned long long remaining = __ballot(live), fallback = 0ull;
+    unsigned long long remaining = __ballot(PHASE != 1 ? live : !done), fallback = 0ull;
     int size = 64;
     while (remaining) {
         const int first = __ffsll((long long)remaining) - 1;
@@ -416,11 +430,10 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         pk_blocks++; pk_ok += P.ok ? 1 : 0;
         // lanes outside the block sit this round out
         const bool done_keep = done;
-        const F3 fo_keep = fo, fd_keep = fd;
-        if (!sel) { done = true; fo = f3(1e18f, 0.0f, 0.0f); fd = f3(0.0f, 0.0f, 0.0f); }
+        if (!sel) done = true;
         if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
             bool out = __all(done);
-            for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+            for (int cb = 0; PHASE != 1 && cb < S.sncl && !out; cb += 64) {
                 const int c = cb + lane;
                 unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
                 if (c < S.sncl && (c % parts) == part) ex_add(ex, EX_PACKET);
@@ -439,12 +452,8 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         mm &= mm - 1;
                         const float4 br = bcast4(mb, u);
                         if (!done) ex_add(ex, EX_FILT);
-                        if (!done && filt_front(fo, fd, br)) {
-                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld, ex)) {
-                                done = true;
-                                fo = f3(1e18f, 0.0f, 0.0f);
-                                fd = f3(0.0f, 0.0f, 0.0f);
-                            }
+                        if (!done && filt_front(o, fd, br)) {
+                            if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld, ex)) done = true;
                         }
                     }
                     out = __all(done);
@@ -461,7 +470,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             //     a.(c - Lr) within [min, max](-D (a.w)) widened by T,
             //     T = R + rperp + (chord |A a^T| / min|ld A| + 0.0112) far + rounding slack,   far >= |c - o|,
             // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
-            if (!out && S.naff > 0 && nlist > 0) {
+            if (PHASE != 0 && !out && S.naff > 0 && nlist > 0) {
                 const F3 Lr = one_light ? apex : P.co;
                 const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
                 const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
@@ -490,18 +499,14 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                         const float4 b0 = bcast4(m0, u), b1 = bcast4(m1, u), b2 = bcast4(m2, u), b3 = bcast4(m3, u);
                         if (!done) ex_add(ex, EX_AFILT);
                         if (!done && !(filt_affine(o, ld, b0, b1, b2, b3) < 0.0f)) {
-                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld, ex)) {
-                                done = true;
-                                fo = f3(1e18f, 0.0f, 0.0f);
-                                fd = f3(0.0f, 0.0f, 0.0f);
-                            }
+                            if (exact_any(S, __float_as_int(b3.y), o, ld, nld, ex)) done = true;
                         }
                     }
                     out = __all(done);
                 }
             }
         }
-        if (!sel) { done = done_keep; fo = fo_keep; fd = fd_keep; }
+        if (!sel) done = done_keep;
     }
     // Rays that fit no packet (abnormal ones included) are traced one at a time, TRANSPOSED: the ray is
     // broadcast and the 64 lanes take 64 different primitives each round, filter and exact test.
@@ -511,10 +516,10 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         fallback &= fallback - 1;
         auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
         const F3 ro = f3(bc(o.x), bc(o.y), bc(o.z)), rl = f3(bc(ld.x), bc(ld.y), bc(ld.z)), rn = f3(bc(nld.x), bc(nld.y), bc(nld.z));
-        const F3 rfo = f3(bc(fo.x), bc(fo.y), bc(fo.z)), rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));
+        const F3 rfo = ro, rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));  // (an abnormal ray bypasses the filter below)
         const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
         bool blocked = false;
-        for (int g = c0 + part * 64; g < c1 && !blocked; g += 64 * parts) {
+        for (int g = c0 + part * 64; PHASE != 1 && g < c1 && !blocked; g += 64 * parts) {
             const int gi = g + lane;
             bool hit = false;
             if (gi < c1) {
@@ -524,7 +529,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             }
             blocked = __any(hit);
         }
-        for (int a0 = part * 64; a0 < S.naff && !blocked; a0 += 64 * parts) {
+        for (int a0 = part * 64; PHASE != 0 && a0 < S.naff && !blocked; a0 += 64 * parts) {
             const int ai = a0 + lane;
             bool hit = false;
             if (ai < S.naff) {
@@ -537,7 +542,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         }
         if (lane == r && blocked) done = true;
     }
-    if (S.pstat && lane == 0) {
+    if (PHASE != 1 && S.pstat && lane == 0) {
         atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
         atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv + ((unsigned long long)pk_aff << 32));
     }
@@ -552,8 +557,27 @@ constexpr int kSplit = 4;
 constexpr int kSplitRays = 1 << 20;   // (re-measured after the edge filter: 2^21 / 2^19 cost 2 ranks 7 %, 8 ranks 4 % of their frame)
 constexpr int kSplitRays8 = 1 << 17;  // ... and by 2 * kSplit workgroups below this
 
+#ifndef RTX_WAVES_SHADOW
+#define RTX_WAVES_SHADOW 4
+#endif
 template <bool EX = false>
-__global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_SHADOW))) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
+{
+    const int n = *cnt_in;
+    const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
+    const int base = (blockIdx.x / parts) * kBlock;
+    if (base >= n) return;  // block-uniform
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    shadow_pass_packet<0>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, nullptr, ex);
+    ex_flush(ex, S.exec + 2 * EX_KINDS);
+}
+
+// PHASE 1 of the pass: the affine spheres, for the rays still lit (launched only when the scene has affine spheres);
+// BOTH = true: PHASE 2, plain primitives and affine spheres in one launch (thin generations).
+template <bool EX = false, bool BOTH = false>
+__global__ __launch_bounds__(kBlock) void k_shadow_affine(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
@@ -563,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_pass(SceneDev S, ShadowQ Qi, 
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
-    shadow_pass_packet(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6], ex);
+    shadow_pass_packet<BOTH ? 2 : 1>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6], ex);
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "librtx.so")
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_DIR, "librtx.so")   # RTX_LIB: A/B builds of the library (tools/dbg)
 RTX_MAX_LEVELS = 32
 F_TIME_KERNELS = 1
 F_COUNT_TESTS = 2
@@ -17,6 +17,7 @@ F_SERIAL = 32
 F_COUNT_EXEC = 64
 F_TRACE_PLANES = 128
 F_TRI_MOLLER_TRUMBORE = 256
+F_WORST_CASE_QUEUES = 512
 RTX_EXEC_KINDS = 16
 EXEC_KERNELS = ("k_closest_f", "k_closest_lanes", "k_shadow_pass")
 EXEC_KINDS = ("packet", "cone", "filt", "afilt", "strip", "sph", "sphx", "tri_early", "tri_cull", "tri_full", "poly", "packets_built", "rays", "tri_edge")
