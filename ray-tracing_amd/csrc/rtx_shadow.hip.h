@@ -438,12 +438,24 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
                 if (c < S.sncl && (c % parts) == part) ex_add(ex, EX_PACKET);
                 pk_batches++;
+                // the members of the NEXT passing cluster are fetched while this one's survivors are traced: a wave walks
+                // ~18 passing clusters, and a full memory round trip in front of each was the longest stall of its life
+                float4 mb_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                int k_n = -1;
+                if (cm && !out) {
+                    const size_t m0 = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+                    mb_n = S.smem[m0];
+                    k_n = S.sidx[m0];
+                }
                 while (cm && !out) {
-                    const int j = __ffsll((long long)cm) - 1;
                     cm &= cm - 1;
-                    const size_t m = (size_t)(cb + j) * 64 + lane;
-                    const float4 mb = S.smem[m];
-                    const int k = S.sidx[m];
+                    const float4 mb = mb_n;
+                    const int k = k_n;
+                    if (cm) {
+                        const size_t m1 = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+                        mb_n = S.smem[m1];
+                        k_n = S.sidx[m1];
+                    }
                     unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
                     if (k >= 0) ex_add(ex, EX_PACKET);
                     pk_batches++; pk_surv += __popcll(mm);
