@@ -172,7 +172,7 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
             name = row["kernel"].replace("rtx::", "")
             if name.startswith("k_affine_cells"):
                 continue
-            if name.startswith("k_raygen"):
+            if name.startswith("k_aa_quantise"):   # one per frame (the calibration pass at context creation has none)
                 frames = float(row["dispatches_per_pass"])
             tot_valu += float(row.get("SQ_INSTS_VALU", 0.0) or 0.0)
             if name.split("<")[0] == dom:

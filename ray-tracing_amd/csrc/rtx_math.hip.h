@@ -197,6 +197,48 @@ __device__ __forceinline__ bool triangle_test_edge(F3 o, F3 dir, const TriRec& T
     return true;
 }
 
+// triangle_test_edge cut in two at the edge filter, for callers that pool the two halves separately (the shadow
+// pass: nine out of ten pairs leave in the first half, and the three square roots of the second run on lanes
+// collected from many pairs instead of on the few of one).  The same binary32 operations in the same order:
+// stage 1 returns 0 = miss (vd == 0, t < 0, edge filter), 1 = the areas decide (t set); stage 2 recomputes
+// P = o + dir t from that t -- the very value triangle_test_edge goes on with -- and returns the test's answer.
+__device__ __forceinline__ int triangle_stage1(F3 o, F3 dir, const float4 q0, const float4 q1, const float4 e0, const float4 e1,
+                                               float& t, int* exitp = nullptr)
+{
+    if (exitp) *exitp = 0;
+    const float vd = q0.x * dir.x + q0.y * dir.y + q0.z * dir.z;
+    if (vd == 0.0f) return 0;
+    t = -((q0.x * o.x + q0.y * o.y + q0.z * o.z) + q0.w) / vd;
+    if (t < 0.0f) return 0;
+    const float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+    const float ax = px - q1.x, ay = py - q1.y, az = pz - q1.z;  // vec1
+    const float q = fabsf(ax) + fabsf(ay) + fabsf(az);
+    const float b1 = e0.x * ax + e0.y * ay + e0.z * az;
+    const float b2 = e1.x * ax + e1.y * ay + e1.z * az;
+    const float b0 = (1.0f - b1) - b2;
+    const float nm = -e0.w;
+    if (exitp) *exitp = 3;
+    if (q <= e1.w && (b1 < nm || b2 < nm || b0 < nm + nm)) return 0;
+    if (exitp) *exitp = 2;
+    return 1;
+}
+
+__device__ __forceinline__ bool triangle_stage2(F3 o, F3 dir, const float t, const float4 q1, const float4 q2, const float4 q3, const float4 q4)
+{
+    const float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+    const float ax = px - q1.x, ay = py - q1.y, az = pz - q1.z;  // vec1
+    const float bx = px - q2.x, by = py - q2.y, bz = pz - q2.z;  // vec2
+    const float v1x = q2.w, v1y = q3.x, v1z = q3.y, v2x = q3.z, v2y = q3.w, v2z = q4.x, ex = q4.y, ey = q4.z, ez = q4.w;
+    const float c1x = ay * v1z - v1y * az, c1y = v1x * az - v1z * ax, c1z = v1y * ax - v1x * ay;
+    const float c2x = az * v2y - ay * v2z, c2y = ax * v2z - az * v2x, c2z = ay * v2x - ax * v2y;
+    const float c3x = bz * ey - by * ez, c3y = bx * ez - bz * ex, c3z = by * ex - bx * ey;
+    const float areau = 0.5f * sqrtf(c2x * c2x + c2y * c2y + c2z * c2z);
+    const float areav = 0.5f * sqrtf(c3x * c3x + c3y * c3y + c3z * c3z);
+    const float areaw = 0.5f * sqrtf(c1x * c1x + c1y * c1y + c1z * c1z);
+    if (fabsf(areau + areav + areaw - q1.w) > 0.01f) return false;
+    return true;
+}
+
 // x*x*x rounded once (error-free products; the tail sum is far below half an ulp), standing in
 // for glibc's pow(x, 3.0) (raytracing.cpp:465) which is correctly rounded in all but
 // vanishingly rare cases; the result is rounded to float right after (see fresnel_term).

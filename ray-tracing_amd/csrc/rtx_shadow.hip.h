@@ -316,6 +316,246 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pooled plain-primitive stage of the shadow pass.
+//
+// The first form of the pass took the survivors of the packet test one at a time: the member record broadcast
+// by four v_readlane, the per-ray filter on SGPR operands (half the issue rate of VGPR operands on this chip,
+// tools/ubench_valu2), and -- under the divergent branch of the lanes that passed -- the exact test of that ONE
+// primitive on a scalar-loaded record: ten odd exact tests per wave with half the lanes live, each behind a
+// scalar-load round trip, the triangles' three square roots run for a handful of lanes.  Profile (r02b): 73 %
+// active lanes, SALU : VALU 0.61.  Here the wave keeps LISTS in LDS and every stage runs on whatever 64 entries
+// are waiting, whichever rays and primitives they belong to (the scheme of closest_pool, stages C / D):
+//   P  the two-level packet test, one sphere per lane (as before)        -> candidates { bound, primitive }
+//   F  eight candidates at a time, read back from LDS at a wave-uniform address (VGPR operands): each lane
+//      = one ray runs the filter on all eight, then the passing (ray, primitive) pairs are pushed, candidate
+//      by candidate, onto the sphere list or the triangle list
+//   S  64 (ray, sphere) pairs: the exact sphere test, one pair per lane; the ray comes by ds_bpermute from
+//      the lane that owns it, the 16-byte hot record by a gather (neighbouring pairs name the same sphere)
+//   T  64 (ray, triangle) pairs: the exact triangle test up to the edge filter (triangle_stage1); the one in
+//      ten that the areas must decide goes onto the area list with its t
+//   A  64 (ray, triangle, t) entries: the three areas (triangle_stage2)
+// A hit sets the ray's flag in LDS; the lanes re-read their flags after every S / T / A step and stop producing
+// pairs.  Any-hit is order-free, so what is tested is a subset of what the one-at-a-time walk tests plus the
+// pairs a ray had already queued when its blocker was found; the answer (some primitive blocks the ray) is the same.
+// ------------------------------------------------------------------------------------------------
+#ifndef RTX_SP_SGPR_PACKET
+#define RTX_SP_SGPR_PACKET 0
+#endif
+constexpr int kSpGroup = 8;              // candidates per filter step
+constexpr int kSpCand = 64 + kSpGroup;   // fewer than a group wait, one push adds up to 64
+constexpr int kSpList = 64 + 64;         // fewer than 64 wait, one push adds up to 64
+
+struct ShadowPoolLds {
+    float4 cb[kSpCand];                  // candidates: filter record { c, -R^2 }
+    int ck[kSpCand];                     //             primitive
+    unsigned listS[kSpList];             // ray << 26 | sphere
+    unsigned listT[kSpList];             // ray << 26 | primitive index of a triangle
+    unsigned listA[kSpList];             // the same, for the area stage
+    float listAt[kSpList];               // ... and the t of its plane intersection
+    int hit[64];                         // 1: some primitive blocks ray r
+};
+
+// idle: this lane's ray takes no part (blocked already, outside the lane block being traced, not a ray).
+// Returns 1 for the lanes whose ray a plain sphere or a triangle of this part's clusters blocks.
+template <bool HASEX>
+__device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet& Pin, ShadowPoolLds& W, const F3 o, const F3 ld, const F3 nld,
+                                                 const F3 fd, const int idle, const int part, const int parts, Exec* ex,
+                                                 int& pk_batches, int& pk_surv)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr unsigned kPrimMask = (1u << kPoolPrimBits) - 1u;
+#if RTX_SP_SGPR_PACKET
+    // the packet is wave-uniform (make_packet ends in wave reductions): held in SGPRs, it frees a dozen VGPRs
+    auto sg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    Packet P;
+    P.co = f3(sg(Pin.co.x), sg(Pin.co.y), sg(Pin.co.z)); P.rho = sg(Pin.rho);
+    P.w = f3(sg(Pin.w.x), sg(Pin.w.y), sg(Pin.w.z)); P.cosT2 = sg(Pin.cosT2); P.sinT = sg(Pin.sinT); P.c0 = Pin.c0; P.ok = Pin.ok;
+#else
+    const Packet& P = Pin;
+#endif
+    W.hit[lane] = 0;
+    lds_fence();
+    int nC = 0, nS = 0, nT = 0, nA = 0;
+    int off = idle;  // (ints, not bools: a bool captured by reference is carried as a byte, see DESIGN.md 4.5 "compiler trap")
+
+    // S: exact sphere tests (raytracing.cpp:202-228, :577-582) of the last cnt (<= 64) entries.  The shadow cluster set
+    // holds no transformed sphere (rtx_pack.cpp: those go through the affine strip test), so the ray is (o, normalize(ld)).
+    auto run_S = [&](const int cnt) {
+        const int base = nS - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listS[base + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rn = f3(__shfl(nld.x, rr), __shfl(nld.y, rr), __shfl(nld.z, rr));
+        const float4 hh = S.sph_hot[k];
+        if (has) ex_add(ex, EX_SPH);
+        float t;
+        const bool hit = sphere_test(ro, rn, hh.x, hh.y, hh.z, hh.w, t);
+        if (has && hit) W.hit[rr] = 1;
+        nS = base;
+        lds_fence();
+    };
+    // A: the three areas (raytracing.cpp:352-365) for the entries the edge filter could not decide
+    auto run_A = [&](const int cnt) {
+        const int base = nA - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listA[base + (has ? lane : 0)];
+        const float t = W.listAt[base + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rl = f3(__shfl(ld.x, rr), __shfl(ld.y, rr), __shfl(ld.z, rr));
+        const float4* p = S.tri_hot + (size_t)(k - S.ns) * 5;
+        const float4 q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+        if (has) ex_add(ex, EX_TRI_FULL);
+        const bool hit = triangle_stage2(ro, rl, t, q1, q2, q3, q4);
+        if (has && hit) W.hit[rr] = 1;
+        nA = base;
+        lds_fence();
+    };
+    // T: the exact triangle test up to the edge filter (raytracing.cpp:338-350 + rtx_bounds.cpp, tri_edge_filter)
+    auto run_T = [&](const int cnt) {
+        const int base = nT - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listT[base + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rl = f3(__shfl(ld.x, rr), __shfl(ld.y, rr), __shfl(ld.z, rr));
+        nT = base;
+        if (S.mt) {  // wave-uniform: RTX_F_TRI_MOLLER_TRUMBORE, one stage
+            const TriRec T = load_tri(S.tri_hot, k - S.ns);
+            float t, vd;
+            if (has) ex_add(ex, EX_TRI_FULL);
+            const bool hit = triangle_test_mt(ro, rl, T, t, vd) && !(t >= __builtin_inff());
+            if (has && hit) W.hit[rr] = 1;
+            lds_fence();
+            return;
+        }
+        const float4* p = S.tri_hot + (size_t)(k - S.ns) * 5;
+        const float4 q0 = p[0], q1 = p[1];
+        const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
+        float t = 0.0f;
+        int exitp = 0;
+        int need = triangle_stage1(ro, rl, q0, q1, e0, e1, t, HASEX ? &exitp : nullptr);
+        if (!has) need = 0;
+        if (HASEX && has && !need) ex_tri(ex, exitp);
+        const unsigned long long bal = __ballot(need != 0);
+        if (bal) {  // wave-uniform
+            if (need) {
+                const int pos = nA + lanes_below(bal);
+                W.listA[pos] = e;
+                W.listAt[pos] = t;
+            }
+            nA += __popcll(bal);
+        }
+        lds_fence();
+        if (nA >= 64) run_A(64);
+    };
+    // F: the per-ray filter on every complete group of kSpGroup candidates, read back from LDS at wave-uniform addresses
+    // (VGPR operands, eight independent chains); the passing (ray, primitive) pairs are pushed candidate by candidate
+    // onto the list of their kind.  What is left over (< kSpGroup) moves to the front.  (One candidate a step, as soon
+    // as a cluster's survivors are known, was measured too: fresher flags, but a ballot and a branch per candidate --
+    // the generation-1 pass took 0.96 ms instead of 0.61.)
+    auto run_F = [&](const int real) {  // real: candidates that are not padding (counting builds)
+        int pos = 0;
+        for (; pos + kSpGroup <= nC; pos += kSpGroup) {
+            unsigned pmask = 0u;
+#pragma unroll
+            for (int v = 0; v < kSpGroup; v++)
+                if (filt_front(o, fd, W.cb[pos + v])) pmask |= 1u << v;
+            if (off) pmask = 0u;
+            if (HASEX && !off) ex_add(ex, EX_FILT, (unsigned)max(0, min(kSpGroup, real - pos)));
+#pragma unroll
+            for (int v = 0; v < kSpGroup; v++) {
+                const bool pass = (pmask >> v) & 1u;
+                const unsigned long long bal = __ballot(pass);
+                if (bal == 0ull) continue;  // wave-uniform
+                const int k = __builtin_amdgcn_readfirstlane(W.ck[pos + v]);  // (read again rather than kept: registers bound this kernel's occupancy)
+                const unsigned ent = ((unsigned)lane << kPoolPrimBits) | (unsigned)k;
+                if (k < S.ns) {
+                    if (pass) W.listS[nS + lanes_below(bal)] = ent;
+                    nS += __popcll(bal);
+                    lds_fence();
+                    if (nS >= 64) { run_S(64); if (W.hit[lane]) { off = 1; pmask = 0u; } }
+                } else {
+                    if (pass) W.listT[nT + lanes_below(bal)] = ent;
+                    nT += __popcll(bal);
+                    lds_fence();
+                    if (nT >= 64) { run_T(64); if (W.hit[lane]) { off = 1; pmask = 0u; } }
+                }
+            }
+        }
+        const int rem = nC - pos;
+        if (pos > 0 && rem > 0) {
+            float4 tb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int tk = 0;
+            if (lane < rem) { tb = W.cb[pos + lane]; tk = W.ck[pos + lane]; }
+            lds_fence();
+            if (lane < rem) { W.cb[lane] = tb; W.ck[lane] = tk; }
+            lds_fence();
+        }
+        nC = rem;
+    };
+
+    // P: the two-level packet test, any order (any-hit); survivors become candidates
+    bool out = __all(off != 0);
+    for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+        const int c = cb + lane;
+        unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+        if (c < S.sncl && (c % parts) == part) ex_add(ex, EX_PACKET);
+        pk_batches++;
+        // the members of the NEXT passing cluster are fetched while this one's are tested
+        float4 mb_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int k_n = -1;
+        if (cm) {
+            const size_t m0 = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+            mb_n = S.smem[m0];
+            k_n = S.sidx[m0];
+        }
+        while (cm && !out) {
+            cm &= cm - 1;
+            const float4 mb = mb_n;
+            const int k = k_n;
+            if (cm) {
+                const size_t m1 = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+                mb_n = S.smem[m1];
+                k_n = S.sidx[m1];
+            }
+            const bool keep = k >= 0 && packet_test(P, mb);
+            const unsigned long long mm = __ballot(keep);
+            if (k >= 0) ex_add(ex, EX_PACKET);
+            pk_batches++; pk_surv += __popcll(mm);
+            if (mm == 0ull) continue;  // wave-uniform
+            if (keep) {
+                const int pos = nC + lanes_below(mm);
+                W.cb[pos] = mb;
+                W.ck[pos] = k;
+            }
+            nC += __popcll(mm);
+            lds_fence();
+            if (nC >= kSpGroup) {
+                run_F(nC);
+                out = __all(off != 0);
+            }
+        }
+    }
+    // what is left: pad the last group with records no ray passes (R^2 = -inf), then drain the lists
+    if (nC > 0 && !out) {
+        const int real = nC;
+        const int padded = (nC + kSpGroup - 1) / kSpGroup * kSpGroup;
+        if (lane >= nC && lane < padded) { W.cb[lane] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff()); W.ck[lane] = S.ns; }
+        nC = padded;
+        lds_fence();
+        run_F(real);
+    }
+    if (!out) {  // (all rays blocked: nothing a queued pair could change)
+        if (nT > 0) run_T(nT);
+        if (nS > 0) run_S(nS);
+        if (nA > 0) run_A(nA);
+    }
+    return W.hit[lane];
+}
+
 constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: every affine sphere is tested
 
 // One shadow pass with the packet test in front of the per-ray filter (see closest_packet).
@@ -326,10 +566,10 @@ constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: e
 // (forcing 6 waves with spills: 5.59 -> 5.20 ms per 4K frame); apart, the traversal takes 65 (7 waves): 5.00 ms.
 // PHASE 2: both in one kernel, the old form -- for thin generations, whose few waves do not fill the SIMDs anyway and
 // which would only pay the second launch.
-template <int PHASE>
+template <int PHASE, bool EXC, bool POOL>
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
                                                    unsigned char* lit, const int lit_cap, const int part, const int parts,
-                                                   unsigned short* alist, Exec* ex)
+                                                   unsigned short* alist, ShadowPoolLds* pool, Exec* ex)
 {
     const int c0 = 0, c1 = S.nsb;
     const int lane = threadIdx.x & 63;
@@ -433,6 +673,12 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         if (!sel) done = true;
         if (P.ok) {  // wave-uniform: two-level packet test, any order (any-hit)
             bool out = __all(done);
+            if constexpr (POOL) {
+            if (PHASE != 1 && !out) {
+                if (shadow_plain_pool<EXC>(S, P, *pool, o, ld, nld, fd, done ? 1 : 0, part, parts, ex, pk_batches, pk_surv)) done = true;
+                out = __all(done);
+            }
+            } else {
             for (int cb = 0; PHASE != 1 && cb < S.sncl && !out; cb += 64) {
                 const int c = cb + lane;
                 unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
@@ -459,6 +705,20 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                     unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
                     if (k >= 0) ex_add(ex, EX_PACKET);
                     pk_batches++; pk_surv += __popcll(mm);
+#ifdef RTX_EXPERIMENT_LAMBDA
+                    // the form DESIGN.md 4.5 reports as having produced wrong lit flags in round 1 (kept out of the build)
+                    auto trace_survivors = [&](const float4& mbr, const int kk, unsigned long long mask) {
+                        while (mask) {
+                            const int u = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const float4 br = bcast4(mbr, u);
+                            if (!done && filt_front(o, fd, br)) {
+                                if (exact_any(S, __builtin_amdgcn_readlane(kk, u), o, ld, nld, ex)) done = true;
+                            }
+                        }
+                    };
+                    trace_survivors(mb, k, mm);
+#else
                     while (mm) {
                         const int u = __ffsll((long long)mm) - 1;
                         mm &= mm - 1;
@@ -468,8 +728,10 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                             if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld, ex)) done = true;
                         }
                     }
+#endif
                     out = __all(done);
                 }
+            }
             }
             // Affine spheres (raytracing.cpp:571-576: only the DIRECTION is mapped, q = ld*A, the origin stays
             // in world space).  Packet test, one sphere per lane: with a reference point Lr (the light, or the
@@ -572,34 +834,37 @@ constexpr int kSplitRays8 = 1 << 17;  // ... and by 2 * kSplit workgroups below 
 #ifndef RTX_WAVES_SHADOW
 #define RTX_WAVES_SHADOW 4
 #endif
-template <bool EX = false>
+template <bool EX = false, bool POOL = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_SHADOW))) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
+    __shared__ ShadowPoolLds pool[POOL ? kBlock / 64 : 1];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
-    shadow_pass_packet<0>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, nullptr, ex);
+    shadow_pass_packet<0, EX, POOL>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, nullptr, &pool[POOL ? (threadIdx.x >> 6) : 0], ex);
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 
 // PHASE 1 of the pass: the affine spheres, for the rays still lit (launched only when the scene has affine spheres);
 // BOTH = true: PHASE 2, plain primitives and affine spheres in one launch (thin generations).
-template <bool EX = false, bool BOTH = false>
+template <bool EX = false, bool BOTH = false, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void k_shadow_affine(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
     __shared__ unsigned short alist[kBlock / 64][kAffListCap];
+    __shared__ ShadowPoolLds pool[(BOTH && POOL) ? kBlock / 64 : 1];  // (PHASE 1 runs no plain stage)
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
-    shadow_pass_packet<BOTH ? 2 : 1>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6], ex);
+    shadow_pass_packet<BOTH ? 2 : 1, EX, POOL>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6],
+                                              &pool[(BOTH && POOL) ? (threadIdx.x >> 6) : 0], ex);
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 

@@ -98,3 +98,28 @@ def test_legacy_grammar_scenes_match_oracle(rt, oracle, gpu, name):
         assert same.mean() >= 0.999, (name, int((~same).sum()))
         rg, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4, flags=flags))
         assert_rgb8_parity(rg, rc, name + " (legacy grammar)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 5])
+def test_pooled_shadow_stage_equals_exact(rt, gpu, tmp_path, monkeypatch, seed):
+    """The opt-in pooled plain-primitive stage of the shadow pass (RTX_SHADOW_POOL_FROM=0: every generation; rtx_shadow.hip.h,
+    shadow_plain_pool -- off by default) gives the image of the exact-only kernels bit for bit: random scenes
+    with affine spheres (fused thin-generation kernel) and a triangle-only scene above 2^20 shadow rays (unsplit launch)."""
+    import numpy as np
+    from parity import raw_equal_mask
+    monkeypatch.setenv("RTX_SHADOW_POOL_FROM", "0")
+    rng = np.random.default_rng(100 + seed)
+    p = tmp_path / ("pool_%d.txt" % seed)
+    lights = [(float(rng.uniform(-45, 45)), float(rng.uniform(-30, 45)), float(rng.uniform(-130, 20)), 0.3, 0.3, 0.3) for _ in range(3)]
+    rt.scenegen.write_scene(str(p), 0 if seed == 5 else 1500, 3000, lights, seed=2000 + seed, frac_affine=0.0 if seed == 5 else 0.3,
+                            frac_reflective=0.5, frac_refractive=0.1, affine="general", radius=(0.3, 3.0), edge=4.0)
+    sc = rt.load_scene(str(p))
+    W, H = (960, 540) if seed == 5 else (480, 270)
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 3))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 3, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    c, sc_ = rt.render_f32(sc, rt.Params.make(W, H, 3, flags=rt.host.F_COUNT_EXEC))  # counting instantiation of the pooled kernels
+    assert raw_equal_mask(a, c).all()
