@@ -367,12 +367,18 @@ def main():
         ctx.render(stream, None)
         img = ctx.read_rgb8()                      # waits for the frame, copies 3 B / pixel to the host
         t1 = time.perf_counter()
-        rgb, _ = rt.render_rgb8(scene, rt.Params.make(W, H, md, device=local_rank))  # create + upload + render + D2H + destroy
+        rt.host.release_cached_context()
+        rgb, _ = rt.render_rgb8(scene, rt.Params.make(W, H, md, device=local_rank))  # create + upload + render + D2H (context kept)
         t2 = time.perf_counter()
-        assert np.array_equal(img, rgb)
-        out["end_to_end"] = {"resident_render_plus_d2h_ms": (t1 - t0) * 1e3, "one_shot_rtx_render_rgb8_ms": (t2 - t1) * 1e3,
-                             "note": "value above is the resident render with the frame left in HBM; these two add the "
-                                     "24.9 MB device-to-host copy, and context creation (scene upload, queue allocation) + teardown"}
+        rgb2, _ = rt.render_rgb8(scene, rt.Params.make(W, H, md, device=local_rank))  # same bytes in: the kept context is reused
+        t3 = time.perf_counter()
+        rt.host.release_cached_context()
+        assert np.array_equal(img, rgb) and np.array_equal(img, rgb2)
+        out["end_to_end"] = {"resident_render_plus_d2h_ms": (t1 - t0) * 1e3, "one_shot_rtx_render_rgb8_first_call_ms": (t2 - t1) * 1e3,
+                             "one_shot_rtx_render_rgb8_next_call_ms": (t3 - t2) * 1e3,
+                             "note": "value above is the resident render with the frame left in HBM; these add the 24.9 MB device-to-host "
+                                     "copy (pageable host buffer), and for the one-shot drop-in call: context creation (scene pack + upload, "
+                                     "cell table, queue allocation, calibration pass) on its first call, a hash of the scene on the next"}
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 0x00030000u
+#define RTX_ABI_VERSION 0x00030100u
 
 /* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
  * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
@@ -132,6 +132,8 @@ typedef struct rtx_params {
                                    counted as parity. */
 #define RTX_F_WORST_CASE_QUEUES 512u /* size every generation's ray queue for fanout^k rays per pixel instead of the counts a
                                    calibration pass measures at creation (A/B aid; same image) */
+#define RTX_F_NO_CACHE   1024u /* one-shot entry points (rtx_render_rgb8 / _f32): create and destroy a context inside the call instead of
+                                   keeping the last one (see rtx_render_rgb8) */
 #define RTX_F_COUNT_EXEC   64u  /* run the counting instantiations of the PRODUCTION intersection kernels (slower: atomics):
                                    what they actually evaluate, by kind -> rtx_stats.exec_counts.  Same image. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
@@ -211,9 +213,16 @@ const char* rtx_last_hip_error(void);
  * params->nranks <= 1 and ngpus > 1 the frame is split into bands of params->band_rows (default 16) rows round-robin
  * over the first `ngpus` devices of this process, one context per device; the 8-bit bands are gathered into device 0
  * with RCCL (grouped ncclSend / ncclRecv over xGMI; librccl.so is loaded on first use, RTX_E_RCCL if that or a
- * collective fails), copied to the host once and put in place in rgb_out.  ngpus beyond the visible devices is clamped. */
+ * collective fails), copied to the host once and put in place in rgb_out.  ngpus beyond the visible devices is clamped.
+ *
+ * The single-device form keeps its context (scene records, cell table, ray queues: HBM) after the call and reuses it when the
+ * next call reads exactly the same bytes -- a 128-bit hash over every record of the scene view, its scalars, the parameters
+ * and the device -- so a host that renders the same scene once per frame pays context creation (45 of 55 ms at 4K) once.  An
+ * edited record gives a new context.  rtx_release_cached_context() frees it; RTX_F_NO_CACHE never keeps one. */
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
                     uint8_t* rgb_out, rtx_stats* stats_or_null);
+/* Frees the context the one-shot entry points keep (no-op if none).  No counterpart in the reference. */
+void rtx_release_cached_context(void);
 
 /* The same call (ngpus = 1) for callers that cannot allocate device memory -- code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference.  Scene records, ray queues, the

@@ -800,16 +800,81 @@ static int context_stats_impl(rtx_context* c, rtx_stats* s)
     return RTX_OK;
 }
 
+// The one-shot entry points keep their LAST context: a drop-in host calls rtx_render_rgb8 once per frame with the same
+// scene and size, and creating a context (scene pack + upload, the affine cell table, queue allocation, the calibration
+// pass) is 45 of the 55 ms such a call takes at 4K.  The context is reused only when a 128-bit hash of EVERYTHING the call
+// reads -- every record of every array of the scene view, its scalars, rtx_params, the device -- equals the cached one
+// (hashing C4's 1.2 MB of records: 0.2 ms), so a caller that edits a record between calls gets a new context.  One entry,
+// held (with its HBM) until a different call replaces it, rtx_release_cached_context() drops it, or the process ends;
+// RTX_F_NO_CACHE bypasses it.  Calls through the cache are serialised.
+struct Hash128 {
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0xc2b2ae3d27d4eb4full;
+    void word(uint64_t w)
+    {
+        a = (a ^ w) * 0x100000001b3ull; a ^= a >> 29;
+        b = (b + w) * 0xff51afd7ed558ccdull; b ^= b >> 32;
+    }
+    void bytes(const void* p, size_t n)
+    {
+        const unsigned char* q = static_cast<const unsigned char*>(p);
+        word(n);
+        for (; n >= 8; n -= 8, q += 8) { uint64_t w; std::memcpy(&w, q, 8); word(w); }
+        if (n) { uint64_t w = 0; std::memcpy(&w, q, n); word(w); }
+    }
+};
+
+static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_t key[2])
+{
+    Hash128 h;
+    h.bytes(sc->spheres, sizeof(rtx_sphere) * (size_t)sc->nspheres);
+    h.bytes(sc->triangles, sizeof(rtx_triangle) * (size_t)sc->ntriangles);
+    h.bytes(sc->planes, sc->planes ? sizeof(rtx_plane) * (size_t)sc->nplanes : 0);
+    h.bytes(sc->lights, sizeof(rtx_light) * (size_t)sc->nlights);
+    h.bytes(sc->polygons, sizeof(rtx_polygon) * (size_t)sc->npolygons);
+    h.bytes(sc->polygon_vertices, sizeof(rtx_vec3) * (size_t)sc->npolygon_vertices);
+    const rtx_vec3 v[5] = { sc->camera, sc->vrp, sc->vpn, sc->up, sc->ambient };
+    h.bytes(v, sizeof v);
+    const int32_t n[8] = { sc->nspheres, sc->ntriangles, sc->nplanes, sc->nlights, sc->npolygons, sc->npolygon_vertices, sc->npolygons_dropped, dev };
+    h.bytes(n, sizeof n);
+    const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
+    h.bytes(q, sizeof q);
+    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) h.bytes(pf, std::strlen(pf));
+    key[0] = h.a; key[1] = h.b;
+}
+
+struct OneShotCache { std::mutex m; rtx_context* c = nullptr; uint64_t key[2] = {0, 0}; };
+static OneShotCache g_one_shot;
+
 static int render_one(const rtx_scene* scene, const rtx_params* params, uint8_t* rgb, float* f32, rtx_stats* stats)
 {
-    rtx_context* c = nullptr;
-    int rc = rtx_context_create(scene, params, &c);
-    if (rc) return rc;
-    rc = rtx_context_render(c, nullptr, nullptr);
-    if (!rc && rgb) rc = rtx_context_read_rgb8(c, rgb);
-    if (!rc && f32) rc = rtx_context_read_f32(c, f32);
-    if (!rc && stats) rc = rtx_context_stats(c, stats);
-    rtx_context_destroy(c);
+    if (params->flags & RTX_F_NO_CACHE) {
+        rtx_context* c = nullptr;
+        int rc = rtx_context_create(scene, params, &c);
+        if (rc) return rc;
+        rc = rtx_context_render(c, nullptr, nullptr);
+        if (!rc && rgb) rc = rtx_context_read_rgb8(c, rgb);
+        if (!rc && f32) rc = rtx_context_read_f32(c, f32);
+        if (!rc && stats) rc = rtx_context_stats(c, stats);
+        rtx_context_destroy(c);
+        return rc;
+    }
+    int dev = params->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;  // (no device: rtx_context_create reports it)
+    uint64_t key[2];
+    hash_call(scene, params, dev, key);
+    std::lock_guard<std::mutex> lk(g_one_shot.m);
+    OneShotCache& C = g_one_shot;
+    if (!C.c || C.key[0] != key[0] || C.key[1] != key[1]) {
+        if (C.c) { rtx_context_destroy(C.c); C.c = nullptr; }
+        int rc = rtx_context_create(scene, params, &C.c);
+        if (rc) { C.c = nullptr; return rc; }
+        C.key[0] = key[0]; C.key[1] = key[1];
+    }
+    int rc = rtx_context_render(C.c, nullptr, nullptr);
+    if (!rc && rgb) rc = rtx_context_read_rgb8(C.c, rgb);
+    if (!rc && f32) rc = rtx_context_read_f32(C.c, f32);
+    if (!rc && stats) rc = rtx_context_stats(C.c, stats);
+    if (rc) { rtx_context_destroy(C.c); C.c = nullptr; }  // never keep a context a call failed on
     return rc;
 }
 
@@ -1149,7 +1214,9 @@ int rtx_render_f32(const rtx_scene* scene, const rtx_params* params, float* out,
     if (!out) return RTX_E_INVALID_ARG;
     int rc = validate(scene, params);
     if (rc) return rc;
+    RTX_TRY
     return render_one(scene, params, nullptr, out, stats);
+    RTX_CATCH
 }
 
 int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params, uint8_t* out, rtx_stats* stats)
@@ -1188,13 +1255,19 @@ int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params, ui
     RTX_CATCH
 }
 
+void rtx_release_cached_context(void)
+{
+    std::lock_guard<std::mutex> lk(g_one_shot.m);
+    if (g_one_shot.c) { rtx_context_destroy(g_one_shot.c); g_one_shot.c = nullptr; }
+}
+
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
 {
     if (!out) return RTX_E_INVALID_ARG;
     int rc = validate(scene, params);
     if (rc) return rc;
-    if (params->nranks > 1 || ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
     RTX_TRY
+    if (params->nranks > 1 || ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
     return render_multi(scene, params, ngpus, out, stats);
     RTX_CATCH
 }

@@ -18,6 +18,7 @@ F_COUNT_EXEC = 64
 F_TRACE_PLANES = 128
 F_TRI_MOLLER_TRUMBORE = 256
 F_WORST_CASE_QUEUES = 512
+F_NO_CACHE = 1024
 RTX_EXEC_KINDS = 16
 EXEC_KERNELS = ("k_closest_f", "k_closest_lanes", "k_shadow_pass")
 EXEC_KINDS = ("packet", "cone", "filt", "afilt", "strip", "sph", "sphx", "tri_early", "tri_cull", "tri_full", "poly", "packets_built", "rays", "tri_edge")
@@ -117,6 +118,7 @@ assert C.sizeof(Plane) == 40 and C.sizeof(Triangle) == 88 and C.sizeof(Light) ==
 # every symbol include/rtx.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rtx_abi_version": (C.c_uint32, []),
+    "rtx_release_cached_context": (None, []),
     "rtx_strerror": (C.c_char_p, [C.c_int]),
     "rtx_device_count": (C.c_int, []),
     "rtx_last_hip_error": (C.c_char_p, []),
@@ -225,6 +227,11 @@ def render_rgb8(scene, params, ngpus=1):
     st = Stats()
     _check(lib().rtx_render_rgb8(scene.ptr, C.byref(params), ngpus, out.ctypes.data, C.byref(st)), "rtx_render_rgb8")
     return out, st
+
+
+def release_cached_context():
+    """rtx_release_cached_context: free the context the one-shot entry points keep between calls."""
+    lib().rtx_release_cached_context()
 
 
 def render_rgb8_noalloc(scene, params):

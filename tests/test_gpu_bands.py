@@ -288,3 +288,36 @@ def test_no_halo_counts_sum_to_the_frame(rt, gpu):
         tot = [tot[0] + st.rays_primary, tot[1] + st.rays_secondary, tot[2] + st.rays_shadow]
         ctx.close()
     assert tot == [full.rays_primary, full.rays_secondary, full.rays_shadow]
+
+
+@pytest.mark.gpu
+def test_one_shot_context_cache(rt, gpu, tmp_path):
+    """rtx_render_rgb8 keeps its context between calls and reuses it only for byte-identical input: the second call
+    returns the same frame (and is not slower than the first by construction), an edited record or parameter gives the
+    frame a fresh context gives (RTX_F_NO_CACHE), and rtx_release_cached_context leaves the entry point working."""
+    import time
+    p = tmp_path / "cache.txt"
+    rt.scenegen.write_scene(str(p), 400, 400, rt.scenegen.lights_c4(), seed=5, frac_affine=0.2, frac_reflective=0.5,
+                            frac_refractive=0.1, affine="general", radius=(1.0, 4.0), edge=8.0)
+    sc = rt.load_scene(str(p))
+    W, H = 640, 360
+    rt.host.release_cached_context()
+    t0 = time.perf_counter(); a, sa = rt.render_rgb8(sc, rt.Params.make(W, H, 3)); t1 = time.perf_counter()
+    b, sb = rt.render_rgb8(sc, rt.Params.make(W, H, 3)); t2 = time.perf_counter()
+    assert np.array_equal(a, b) and sa.rays_total == sb.rays_total
+    fresh, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 3, flags=rt.host.F_NO_CACHE))
+    assert np.array_equal(a, fresh)
+    print("one-shot: first %.1f ms, cached %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    # an edited record must not be answered from the cache
+    sc.view.spheres[0].color.x = 0.0 if sc.view.spheres[0].color.x else 1.0
+    sc.view.spheres[0].radius *= 3.0
+    c, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 3))
+    cf, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 3, flags=rt.host.F_NO_CACHE))
+    assert np.array_equal(c, cf) and not np.array_equal(c, a)
+    # another depth: another context
+    d, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 1))
+    df, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 1, flags=rt.host.F_NO_CACHE))
+    assert np.array_equal(d, df)
+    rt.host.release_cached_context()
+    e, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 1))
+    assert np.array_equal(e, d)
