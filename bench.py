@@ -133,7 +133,9 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
                 flops_per_test=EXEC_FLOPS,
                 note="achieved = FLOPs of the tests this kernel EXECUTES (rtx_stats.exec_counts of a counting frame x flops_per_test) "
                      "/ its summed launch time in a serial frame (RTX_F_SERIAL, HIP events; nothing overlaps); frame.* = the three "
-                     "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.")
+                     "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.  "
+                     "k_shadow_pass = one timed bracket per generation: the traversal kernel k_shadow_pass plus the affine-sphere kernel "
+                     "k_shadow_affine behind it (or the fused k_shadow_affine<.,true> of a thin generation).")
     # (c) what the reference's brute-force loops would execute for the same rays, and the exact-only kernels' own fraction
     bw, bh = (W, H) if args.workload != "c5" else (W // 16, H // 16)   # C5 brute force at full size is minutes per frame
     import rtxamd as rt_
@@ -168,6 +170,9 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
     if full:
         src, rows = pmc_summary(args.workload)
         frames, tot_valu = None, 0.0
+        # the timed bracket of a shadow generation holds the traversal kernel AND the affine-sphere kernel behind it
+        group = ("k_shadow_pass", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
+        acc = {}
         for row in rows:
             name = row["kernel"].replace("rtx::", "")
             if name.startswith("k_affine_cells"):
@@ -175,20 +180,24 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
             if name.startswith("k_aa_quantise"):   # one per frame (the calibration pass at context creation has none)
                 frames = float(row["dispatches_per_pass"])
             tot_valu += float(row.get("SQ_INSTS_VALU", 0.0) or 0.0)
-            if name.split("<")[0] == dom:
-                launches = max(float(row["dispatches_per_pass"]), 1.0)
-                g = lambda k: float(row.get(k, 0.0) or 0.0)
-                if g("FETCH_SIZE") or g("WRITE_SIZE"):
-                    # the guide's gfx950 correction: FETCH_SIZE tallies wide (16 B / lane) reads at half their bytes; the
-                    # kernel mixes widths, so the doubled figure is an upper bound
-                    roof["traffic"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 / launches
-                    roof["traffic_note"] = "HBM bytes per launch from %s (FETCH_SIZE x 2 + WRITE_SIZE, KB): an upper bound" % src
-                if g("SQ_INSTS_VALU"):
-                    roof["active_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_ACTIVE_INST_VALU") * 64.0, 1.0) if g("SQ_ACTIVE_INST_VALU") else None
-                    roof["salu_per_valu"] = g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU")
-                if g("SQ_BUSY_CYCLES"):
-                    roof["occupancy_waves_per_simd"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES") / 4.0 if g("SQ_WAVE_CYCLES") else None
-                roof["pmc_source"] = src
+            if name.split("<")[0] in group:
+                for k, v in row.items():
+                    if k not in ("kernel", "vgpr", "lds_bytes", "dispatches_per_pass"):
+                        acc[k] = acc.get(k, 0.0) + float(v or 0.0)
+        if acc and frames:
+            g = lambda k: acc.get(k, 0.0)
+            launches = frames * max(d["launches"], 1)
+            if g("FETCH_SIZE") or g("WRITE_SIZE"):
+                # the guide's gfx950 correction: FETCH_SIZE tallies wide (16 B / lane) reads at half their bytes; the
+                # kernel mixes widths, so the doubled figure is an upper bound
+                roof["traffic"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 / launches
+                roof["traffic_note"] = "HBM bytes per timed launch bracket from %s (FETCH_SIZE x 2 + WRITE_SIZE, KB): an upper bound" % src
+            if g("SQ_INSTS_VALU"):
+                roof["active_lane_frac"] = g("SQ_THREAD_CYCLES_VALU") / max(g("SQ_ACTIVE_INST_VALU") * 64.0, 1.0) if g("SQ_ACTIVE_INST_VALU") else None
+                roof["salu_per_valu"] = g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU")
+            if g("SQ_BUSY_CYCLES"):
+                roof["occupancy_waves_per_simd"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES") / 4.0 if g("SQ_WAVE_CYCLES") else None
+            roof["pmc_source"] = src
         if frames and tot_valu:
             per_frame = tot_valu / frames
             rate = per_frame / (st_timed.ms_total * 1e-3) / 1e9
