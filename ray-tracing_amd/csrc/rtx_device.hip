@@ -188,6 +188,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->params = *params;
     c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
     if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // opt-in experiment / A-B aid; same image either way
+    if (const char* e4 = std::getenv("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
+    if (const char* e8 = std::getenv("RTX_SPLIT8")) c->split8 = std::atoi(e8);
     c->width = params->width;
     c->height = params->height;
     const int W = c->width, H = c->height;

@@ -317,7 +317,9 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pooled plain-primitive stage of the shadow pass.
+// Pooled plain-primitive stage of the shadow pass -- an OPT-IN EXPERIMENT (RTX_SHADOW_POOL_FROM=k: generations >= k
+// take it), off by default: bit-identical, faster for incoherent generations of a few million rays, slower for the
+// coherent generation 0 and for triangle-only scenes of 10^5 primitives (measurements: DESIGN.md 4.7).
 //
 // The first form of the pass took the survivors of the packet test one at a time: the member record broadcast
 // by four v_readlane, the per-ray filter on SGPR operands (half the issue rate of VGPR operands on this chip,
