@@ -918,7 +918,10 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 // Generations of at most kSplitClosest rays give a wave 16 rays instead of 64 (64 rays per workgroup): a thin
 // generation has fewer waves than the chip has SIMDs, its run time is one wave's serial walk, and the pooled
 // stages keep all 64 lanes busy whatever the number of rays.
-constexpr int kSplitClosest = 1 << 17;
+#ifndef RTX_SPLIT_CLOSEST_LOG2
+#define RTX_SPLIT_CLOSEST_LOG2 17
+#endif
+constexpr int kSplitClosest = 1 << RTX_SPLIT_CLOSEST_LOG2;
 constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
 #ifndef RTX_WAVES_LANES
