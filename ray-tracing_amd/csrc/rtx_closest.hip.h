@@ -214,9 +214,40 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 
 struct Packet { F3 co; float rho; F3 w; float cosT2, sinT; float c0; bool ok; };  // c0 = cos(theta), rounded down, before the widening by E
 
+// Wave reductions for the BOUNDS (packets): four DPP steps reduce each row of 16 lanes in place (quad swaps, half-row
+// and row mirrors: register-to-register, no LDS round trip), the four row results are read with v_readlane and
+// combined -- the result is wave-uniform and lands in an SGPR.  (The ds_bpermute butterfly this replaces was six
+// dependent LDS-pipeline round trips per reduction, five reductions per packet.)  All 64 lanes must be active.
+#ifndef RTX_DPP_REDUCE
+#define RTX_DPP_REDUCE 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+#if RTX_DPP_REDUCE
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); v = fminf(v, dpp_f<0x141>(v)); v = fminf(v, dpp_f<0x140>(v));
+    return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+#else
 __device__ __forceinline__ float wave_min(float v) { for (int m = 32; m; m >>= 1) v = fminf(v, __shfl_xor(v, m)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int m = 32; m; m >>= 1) v = fmaxf(v, __shfl_xor(v, m)); return v; }
 __device__ __forceinline__ float wave_sum(float v) { for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m); return v; }
+#endif
 
 // apex_ok: every line of the wave passes through `apex` (shadow rays: their light); the origin sphere then
 // shrinks to the slack that claim needs (the 1e-4 origin bias, the filter's angular tolerance and the
