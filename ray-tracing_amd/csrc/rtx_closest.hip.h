@@ -261,8 +261,9 @@ __device__ __forceinline__ Packet make_packet(F3 o, F3 nd, bool live, bool abn, 
     // dead lanes borrow a live lane's ray so they do not widen the bounds
     // (the shuffles are evaluated by EVERY lane, outside the selects: a ds_bpermute under a divergent branch
     // reads 0 from the lanes that did not take the branch)
-    const F3 so = f3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-    const F3 sd = f3(__shfl(nd.x, src), __shfl(nd.y, src), __shfl(nd.z, src));
+    // (src is wave-uniform: v_readlane, no LDS round trip)
+    const F3 so = f3(lane_f(o.x, src), lane_f(o.y, src), lane_f(o.z, src));
+    const F3 sd = f3(lane_f(nd.x, src), lane_f(nd.y, src), lane_f(nd.z, src));
     F3 oo = f3(live ? o.x : so.x, live ? o.y : so.y, live ? o.z : so.z);
     F3 dd = f3(live ? nd.x : sd.x, live ? nd.y : sd.y, live ? nd.z : sd.z);
     if (apex_ok) {  // wave-uniform: one reduction instead of the seven of the origins' bounding sphere
@@ -364,7 +365,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
     // generation 0 only: every ray leaves the camera, the packet's apex (one wave reduction instead of seven)
     const unsigned long long lm0 = __ballot(live);
     const int src0 = lm0 ? (__ffsll((long long)lm0) - 1) : 0;
-    const F3 cam = f3(__shfl(o.x, src0), __shfl(o.y, src0), __shfl(o.z, src0));
+    const F3 cam = f3(lane_f(o.x, src0), lane_f(o.y, src0), lane_f(o.z, src0));
     const bool one_origin = __all(!live || (o.x == cam.x && o.y == cam.y && o.z == cam.z));
     const Packet P = make_packet(o, nd, live, abn, one_origin, cam);
     if (lane == 0) ex_add(ex, EX_WAVES);
@@ -441,7 +442,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                 const int up = __shfl_up(incl, off);
                 if (lane >= off) incl += up;
             }
-            const int tot = __shfl(incl, 63);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
             if (tot == 0) continue;  // wave-uniform
             {
                 unsigned bits = wv;

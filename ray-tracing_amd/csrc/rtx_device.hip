@@ -117,8 +117,8 @@ struct rtx_context {
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
     hipStream_t last_stream = nullptr;
-    int pool_from = 1 << 30;                // first generation whose shadow pass takes the pooled stages (shadow_plain_pool); off by
-                                            // default -- measured slower or equal on C4 and C5, DESIGN.md 4.7 -- RTX_SHADOW_POOL_FROM=k turns it on
+    int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
+                                            // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
     bool rendered = false;
     int nchunks = 0;
@@ -187,7 +187,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->device = dev;
     c->params = *params;
     c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
-    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // opt-in experiment / A-B aid; same image either way
+    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
     if (const char* e4 = std::getenv("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
     if (const char* e8 = std::getenv("RTX_SPLIT8")) c->split8 = std::atoi(e8);
     c->width = params->width;
@@ -706,7 +706,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 // scenes with affine spheres: a generation that can fill the chip runs the traversal of the plain primitives
                 // and the affine spheres as two kernels (registers: 65 / 93 VGPRs instead of 104 together), a thin one as one
                 const bool fused = c->S.naff > 0 && live_cap * (size_t)c->S.nl <= (size_t)c->split4;
-                // the pooled stages (rtx_shadow.hip.h, shadow_plain_pool) from generation pool_from on: an opt-in experiment
+                // generation 0's shadow rays (hits of primary rays) are coherent enough for the one-survivor-at-a-time walk;
+                // later generations take the pooled stages (rtx_shadow.hip.h, shadow_plain_pool)
                 const bool pool = k >= c->pool_from;
 #define RTX_SHADOW_ARGS dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8
                 if (fused) {

@@ -153,7 +153,7 @@ __device__ __forceinline__ int wave_alloc(bool want, int* counter)
     int leader = __ffsll((long long)m) - 1;
     int base = 0;
     if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader);
+    base = __builtin_amdgcn_readlane(base, leader);
     return want ? base + prefix : -1;
 }
 

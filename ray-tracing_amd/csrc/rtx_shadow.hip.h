@@ -341,9 +341,6 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 // pairs.  Any-hit is order-free, so what is tested is a subset of what the one-at-a-time walk tests plus the
 // pairs a ray had already queued when its blocker was found; the answer (some primitive blocks the ray) is the same.
 // ------------------------------------------------------------------------------------------------
-#ifndef RTX_SP_SGPR_PACKET
-#define RTX_SP_SGPR_PACKET 0
-#endif
 constexpr int kSpGroup = 8;              // candidates per filter step
 constexpr int kSpCand = 64 + kSpGroup;   // fewer than a group wait, one push adds up to 64
 constexpr int kSpList = 64 + 64;         // fewer than 64 wait, one push adds up to 64
@@ -362,20 +359,12 @@ struct ShadowPoolLds {
 // Returns 1 for the lanes whose ray a plain sphere or a triangle of this part's clusters blocks.
 template <bool HASEX>
 __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet& Pin, ShadowPoolLds& W, const F3 o, const F3 ld, const F3 nld,
-                                                 const F3 fd, const int idle, const int part, const int parts, Exec* ex,
+                                                 const int idle, const int part, const int parts, Exec* ex,
                                                  int& pk_batches, int& pk_surv)
 {
     const int lane = threadIdx.x & 63;
     constexpr unsigned kPrimMask = (1u << kPoolPrimBits) - 1u;
-#if RTX_SP_SGPR_PACKET
-    // the packet is wave-uniform (make_packet ends in wave reductions): held in SGPRs, it frees a dozen VGPRs
-    auto sg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    Packet P;
-    P.co = f3(sg(Pin.co.x), sg(Pin.co.y), sg(Pin.co.z)); P.rho = sg(Pin.rho);
-    P.w = f3(sg(Pin.w.x), sg(Pin.w.y), sg(Pin.w.z)); P.cosT2 = sg(Pin.cosT2); P.sinT = sg(Pin.sinT); P.c0 = Pin.c0; P.ok = Pin.ok;
-#else
     const Packet& P = Pin;
-#endif
     W.hit[lane] = 0;
     lds_fence();
     int nC = 0, nS = 0, nT = 0, nA = 0;
@@ -460,6 +449,8 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
     // the generation-1 pass took 0.96 ms instead of 0.61.)
     auto run_F = [&](const int real) {  // real: candidates that are not padding (counting builds)
         int pos = 0;
+        // (the filter's scaled direction is derived here rather than carried through the exact stages: registers)
+        const F3 fd = f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale);
         for (; pos + kSpGroup <= nC; pos += kSpGroup) {
             unsigned pmask = 0u;
 #pragma unroll
@@ -626,7 +617,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             unsigned long long pending = __ballot(key >= 0);
             while (pending) {
                 const int leader = __ffsll((long long)pending) - 1;
-                const int k0 = __shfl(key, leader);
+                const int k0 = __builtin_amdgcn_readlane(key, leader);
                 pending &= ~__ballot(key == k0);
                 if (lane < S.aff_words) acc |= S.aff_cells[(size_t)k0 * S.aff_words + lane];
             }
@@ -637,7 +628,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
                 const int up = __shfl_up(incl, off);
                 if (lane >= off) incl += up;
             }
-            const int total = __shfl(incl, 63);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total <= kAffListCap) {
                 int pos = incl - cnt;
                 while (acc) {
@@ -677,7 +668,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             bool out = __all(done);
             if constexpr (POOL) {
             if (PHASE != 1 && !out) {
-                if (shadow_plain_pool<EXC>(S, P, *pool, o, ld, nld, fd, done ? 1 : 0, part, parts, ex, pk_batches, pk_surv)) done = true;
+                if (shadow_plain_pool<EXC>(S, P, *pool, o, ld, nld, done ? 1 : 0, part, parts, ex, pk_batches, pk_surv)) done = true;
                 out = __all(done);
             }
             } else {
@@ -748,7 +739,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             // (a.(delta A) = delta.(A a^T); |s| <= |p - o| / |ld A|).  Everything else is skipped for the whole block.
             if (PHASE != 0 && !out && S.naff > 0 && nlist > 0) {
                 const F3 Lr = one_light ? apex : P.co;
-                const F3 so = f3(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
+                const F3 so = f3(lane_f(o.x, first), lane_f(o.y, first), lane_f(o.z, first));
                 const F3 oo = f3(sel ? o.x : so.x, sel ? o.y : so.y, sel ? o.z : so.z);  // lanes outside the block borrow a ray of it
                 const F3 rel = f3(Lr.x - oo.x, Lr.y - oo.y, Lr.z - oo.z);
                 const float D = P.w.x * rel.x + P.w.y * rel.y + P.w.z * rel.z;
@@ -792,7 +783,7 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         fallback &= fallback - 1;
         auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
         const F3 ro = f3(bc(o.x), bc(o.y), bc(o.z)), rl = f3(bc(ld.x), bc(ld.y), bc(ld.z)), rn = f3(bc(nld.x), bc(nld.y), bc(nld.z));
-        const F3 rfo = ro, rfd = f3(bc(fd.x), bc(fd.y), bc(fd.z));  // (an abnormal ray bypasses the filter below)
+        const F3 rfo = ro, rfd = f3(rn.x * kDirScale, rn.y * kDirScale, rn.z * kDirScale);  // (an abnormal ray bypasses the filter below)
         const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
         bool blocked = false;
         for (int g = c0 + part * 64; PHASE != 1 && g < c1 && !blocked; g += 64 * parts) {
@@ -836,8 +827,11 @@ constexpr int kSplitRays8 = 1 << 17;  // ... and by 2 * kSplit workgroups below 
 #ifndef RTX_WAVES_SHADOW
 #define RTX_WAVES_SHADOW 4
 #endif
+#ifndef RTX_WAVES_POOL
+#define RTX_WAVES_POOL 4
+#endif
 template <bool EX = false, bool POOL = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_SHADOW))) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(POOL ? RTX_WAVES_POOL : RTX_WAVES_SHADOW))) void k_shadow_pass(SceneDev S, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap, int split4, int split8)
 {
     const int n = *cnt_in;
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
