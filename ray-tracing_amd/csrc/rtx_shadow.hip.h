@@ -582,7 +582,10 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
     F3 fd = use ? f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
     bool done = !live;
     if (PHASE == 1) {
-        if (live && lit[id] == 0) done = true;   // blocked by a plain primitive already (PHASE 0, same stream)
+        // rays a plain primitive blocks were taken out of the queue by PHASE 0 (same stream): their record's id is < 0 and
+        // they are not `live` here -- no gather of lit[] bytes in front of this kernel.  A split launch (several workgroups
+        // per 256 rays, each clearing lit[] for its share of the clusters) cannot edit the queue it is still reading:
+        if (parts != 1 && live && lit[id] == 0) done = true;
         if (__all(done)) return;                  // wave-uniform
     }
     if (PHASE != 1 && live && part == 0) ex_add(ex, EX_RAYS);
@@ -813,7 +816,12 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
         atomicAdd(S.pstat + 4, (unsigned long long)pk_blocks); atomicAdd(S.pstat + 5, (unsigned long long)pk_ok + ((unsigned long long)pk_fb << 32));
         atomicAdd(S.pstat + 6, (unsigned long long)pk_batches); atomicAdd(S.pstat + 7, (unsigned long long)pk_surv + ((unsigned long long)pk_aff << 32));
     }
-    if (live && done) lit[id] = 0;
+    if (live && done) {
+        lit[id] = 0;
+        // PHASE 0 with an affine kernel behind it (unsplit launches only: rtx_device.hip): the ray leaves the queue, so
+        // PHASE 1 neither reads its lit byte (a scattered gather) nor traces it
+        if (PHASE == 0 && S.naff > 0 && parts == 1) reinterpret_cast<int*>(Qi.b + i)[2] = -2;
+    }
 }
 
 // A thin generation (<= kSplitRays shadow rays) is traced by kSplit workgroups per 256 rays, each taking every
