@@ -317,16 +317,16 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pooled plain-primitive stage of the shadow pass -- an OPT-IN EXPERIMENT (RTX_SHADOW_POOL_FROM=k: generations >= k
-// take it), off by default: bit-identical, faster for incoherent generations of a few million rays, slower for the
-// coherent generation 0 and for triangle-only scenes of 10^5 primitives (measurements: DESIGN.md 4.7).
+// Pooled plain-primitive stage of the shadow pass: what generations >= 1 run (rtx_context::pool_from; generation 0's
+// coherent rays keep the one-survivor-at-a-time walk, which is faster there).  Bit-identical either way; measurements in
+// DESIGN.md 4.4 / 4.7.
 //
 // The first form of the pass took the survivors of the packet test one at a time: the member record broadcast
 // by four v_readlane, the per-ray filter on SGPR operands (half the issue rate of VGPR operands on this chip,
 // tools/ubench_valu2), and -- under the divergent branch of the lanes that passed -- the exact test of that ONE
 // primitive on a scalar-loaded record: ten odd exact tests per wave with half the lanes live, each behind a
 // scalar-load round trip, the triangles' three square roots run for a handful of lanes.  Profile (r02b): 73 %
-// active lanes, SALU : VALU 0.61.  Here the wave keeps LISTS in LDS and every stage runs on whatever 64 entries
+// active lanes, SALU : VALU 0.61 (this stage, r02e: 94 %, 0.35).  Here the wave keeps LISTS in LDS and every stage runs on whatever 64 entries
 // are waiting, whichever rays and primitives they belong to (the scheme of closest_pool, stages C / D):
 //   P  the two-level packet test, one sphere per lane (as before)        -> candidates { bound, primitive }
 //   F  eight candidates at a time, read back from LDS at a wave-uniform address (VGPR operands): each lane
