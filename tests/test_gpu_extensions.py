@@ -103,9 +103,10 @@ def test_legacy_grammar_scenes_match_oracle(rt, oracle, gpu, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 3, 5])
 def test_pooled_shadow_stage_equals_exact(rt, gpu, tmp_path, monkeypatch, seed):
-    """The opt-in pooled plain-primitive stage of the shadow pass (RTX_SHADOW_POOL_FROM=0: every generation; rtx_shadow.hip.h,
-    shadow_plain_pool -- off by default) gives the image of the exact-only kernels bit for bit: random scenes
-    with affine spheres (fused thin-generation kernel) and a triangle-only scene above 2^20 shadow rays (unsplit launch)."""
+    """The pooled plain-primitive stage of the shadow pass (rtx_shadow.hip.h, shadow_plain_pool: generations >= 1 by
+    default, here EVERY generation with RTX_SHADOW_POOL_FROM=0) gives the image of the exact-only kernels bit for bit:
+    random scenes with affine spheres (fused thin-generation kernel) and a triangle-only scene above 2^20 shadow rays
+    (unsplit launch); then the same scenes with the stage off everywhere (the one-at-a-time walk in every generation)."""
     import numpy as np
     from parity import raw_equal_mask
     monkeypatch.setenv("RTX_SHADOW_POOL_FROM", "0")
@@ -123,3 +124,24 @@ def test_pooled_shadow_stage_equals_exact(rt, gpu, tmp_path, monkeypatch, seed):
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
     c, sc_ = rt.render_f32(sc, rt.Params.make(W, H, 3, flags=rt.host.F_COUNT_EXEC))  # counting instantiation of the pooled kernels
     assert raw_equal_mask(a, c).all()
+    monkeypatch.setenv("RTX_SHADOW_POOL_FROM", "99")
+    w, sw = rt.render_f32(sc, rt.Params.make(W, H, 3))
+    assert raw_equal_mask(a, w).all() and sw.rays_shadow == sa.rays_shadow
+
+
+def test_calibrated_queues_equal_worst_case_queues(rt, gpu, tmp_path):
+    """Ray queues sized by the calibration pass (the default) against queues sized for fanout^k rays per pixel
+    (RTX_F_WORST_CASE_QUEUES): same image, same ray counts, nothing dropped -- on a scene whose primitives both reflect
+    and refract (fan-out 2), at a depth where the worst case is 31 x the pixel count."""
+    from parity import raw_equal_mask
+    p = tmp_path / "fan2.txt"
+    rt.scenegen.write_scene(str(p), 600, 600, rt.scenegen.lights_c4(), seed=77, frac_affine=0.2, frac_reflective=0.7,
+                            frac_refractive=0.5, affine="diag", radius=(1.0, 4.0), edge=8.0)
+    sc = rt.load_scene(str(p))
+    W, H = 480, 270
+    a, sa = rt.render_f32(sc, rt.Params.make(W, H, 4))
+    b, sb = rt.render_f32(sc, rt.Params.make(W, H, 4, flags=rt.host.F_WORST_CASE_QUEUES))
+    assert raw_equal_mask(a, b).all()
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert sa.queue_overflow == 0 and sb.queue_overflow == 0
+    assert sa.rays_secondary > W * H  # the scene really fans out
