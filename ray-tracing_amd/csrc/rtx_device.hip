@@ -295,6 +295,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.cnfirst = P.cc.nfirst;
             if ((rc = up4(P.sc.cl, &c->S.scl))) return rc;
             if ((rc = up4(P.sc.mem, &c->S.smem))) return rc;
+            if ((rc = up4(P.sc.subR, &c->S.ssubR))) return rc;
             if ((rc = c->upload(&q, P.sc.idx))) return rc;
             c->S.sidx = q;
             c->S.sncl = (int)P.sc.cl.size();
@@ -537,6 +538,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->calibrated = true;
     }
     c->chunk_rows = (int)rows;
+    // Two-level member selection in the shadow pass (rtx_shadow.hip.h, shadow_select) for frames that fill the chip:
+    // chunks of >= 2^22 primary rays (a whole 4K frame or half of one; any 8K share).  Thinner frames -- a rank of 4 or 8
+    // of the 4K frame -- are bound by a wave's chain of dependent steps, which the extra level lengthens.  RTX_TWO_LEVEL=0/1
+    // forces it (A/B aid; same image).
+    c->S.sel2 = ((int64_t)rows * W >= ((int64_t)1 << 22)) ? 1 : 0;
+    if (const char* e2 = std::getenv("RTX_TWO_LEVEL")) c->S.sel2 = std::atoi(e2) ? 1 : 0;
     if ((rc = alloc_levels(caps, true))) return rc;
     {   // shadow-ray queues: the largest generation's hits x lights
         size_t mx = 0;
@@ -841,7 +848,8 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) h.bytes(pf, std::strlen(pf));
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL"})  // the A/B aids context creation reads
+        if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }
 

@@ -317,6 +317,78 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-level member selection of the shadow pass (round 2).  A passing cluster used to cost one packet-test step over
+// its 64 members, of which two in a hundred survive.  Now the passing clusters of a batch are written out as a list and
+// taken EIGHT at a time: lane = (cluster j, sub-cluster s) tests the sphere around members 8s .. 8s+7 (ClusterSet::subR,
+// built for the per-ray traversal of closest hit and now uploaded for the shadow set too); the passing sub-clusters are
+// listed in turn and taken eight at a time, lane = (sub-cluster, member).  A sub-cluster sphere encloses its members'
+// filter spheres (rtx_pack.cpp, enclose: radius from the binary32-rounded centre, rounded up), so a member some ray of the
+// packet can pass lies in a sub-cluster that passes -- the argument that already covers the cluster level.
+// visit(mb, k, keep, mm) sees 64 members at a time, `keep` lanes being survivors (mask mm != 0); it returns 1 when the
+// wave has nothing left to trace.
+// ------------------------------------------------------------------------------------------------
+struct ShadowSelLds { int clist[64]; int slist[64]; };
+
+// packet_test for a sphere given as { c, R }
+__device__ __forceinline__ bool packet_test_R(const Packet& P, float4 b)
+{
+    float Cx = b.x - P.co.x, Cy = b.y - P.co.y, Cz = b.z - P.co.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;
+    float Rp = (b.w * 1.00001f + P.rho) * 1.00001f + 1e-20f;
+    float rhs = Rp + a * P.sinT;
+    return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // R = +inf (clusters of never-bounded primitives) passes
+}
+
+template <typename Visit>
+__device__ __forceinline__ int shadow_select(const SceneDev& S, const Packet& P, ShadowSelLds& L, const int part, const int parts,
+                                             Exec* ex, int& pk_batches, int& pk_surv, Visit&& visit)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane >> 3;
+    int out = 0;
+    for (int cb = 0; cb < S.sncl && !out; cb += 64) {
+        const int c = cb + lane;
+        const bool mine = c < S.sncl && (c % parts) == part;
+        const bool cpass = mine && packet_test(P, S.scl[min(c, S.sncl - 1)]);
+        const unsigned long long cm = __ballot(cpass);
+        if (mine) ex_add(ex, EX_PACKET);
+        pk_batches++;
+        if (cm == 0ull) continue;  // wave-uniform
+        const int nc = __popcll(cm);
+        if (cpass) L.clist[lanes_below(cm)] = c;
+        lds_fence();
+        for (int c0 = 0; c0 < nc && !out; c0 += 8) {
+            const bool v1 = c0 + j < nc;
+            const int sid0 = L.clist[min(c0 + j, nc - 1)] * 8 + (lane & 7);
+            const bool spass = v1 && packet_test_R(P, S.ssubR[sid0]);
+            if (v1) ex_add(ex, EX_PACKET);
+            const unsigned long long sm = __ballot(spass);
+            pk_batches++;
+            if (sm == 0ull) continue;
+            const int ns = __popcll(sm);
+            if (spass) L.slist[lanes_below(sm)] = sid0;
+            lds_fence();
+            for (int s0 = 0; s0 < ns && !out; s0 += 8) {
+                const bool v2 = s0 + j < ns;
+                const size_t mi = (size_t)L.slist[min(s0 + j, ns - 1)] * 8 + (lane & 7);
+                const float4 mb = S.smem[mi];
+                const int k = v2 ? S.sidx[mi] : -1;
+                const bool keep = k >= 0 && packet_test(P, mb);
+                if (k >= 0) ex_add(ex, EX_PACKET);
+                const unsigned long long mm = __ballot(keep);
+                pk_batches++; pk_surv += __popcll(mm);
+                if (mm != 0ull) out = visit(mb, k, keep, mm);
+            }
+            lds_fence();  // the next round of sub-clusters rewrites slist
+        }
+        lds_fence();  // the next batch rewrites clist
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pooled plain-primitive stage of the shadow pass: what generations >= 1 run (rtx_context::pool_from; generation 0's
 // coherent rays keep the one-survivor-at-a-time walk, which is faster there).  Bit-identical either way; measurements in
 // DESIGN.md 4.4 / 4.7.
@@ -358,7 +430,7 @@ struct ShadowPoolLds {
 // idle: this lane's ray takes no part (blocked already, outside the lane block being traced, not a ray).
 // Returns 1 for the lanes whose ray a plain sphere or a triangle of this part's clusters blocks.
 template <bool HASEX>
-__device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet& Pin, ShadowPoolLds& W, const F3 o, const F3 ld, const F3 nld,
+__device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet& Pin, ShadowPoolLds& W, ShadowSelLds& Lsel, const bool two, const F3 o, const F3 ld, const F3 nld,
                                                  const int idle, const int part, const int parts, Exec* ex,
                                                  int& pk_batches, int& pk_surv)
 {
@@ -490,8 +562,25 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
         nC = rem;
     };
 
-    // P: the two-level packet test, any order (any-hit); survivors become candidates
+    // P: the packet test down the hierarchy, any order (any-hit); survivors become candidates
     bool out = __all(off != 0);
+    if (two) {
+      if (!out) {
+        out = shadow_select(S, P, Lsel, part, parts, ex, pk_batches, pk_surv,
+                            [&](const float4 mb, const int k, const bool keep, const unsigned long long mm) -> int {
+            if (keep) {
+                const int pos = nC + lanes_below(mm);
+                W.cb[pos] = mb;
+                W.ck[pos] = k;
+            }
+            nC += __popcll(mm);
+            lds_fence();
+            if (nC < kSpGroup) return 0;
+            run_F(nC);
+            return __all(off != 0) ? 1 : 0;
+        }) != 0;
+      }
+    } else {
     for (int cb = 0; cb < S.sncl && !out; cb += 64) {
         const int c = cb + lane;
         unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
@@ -532,6 +621,7 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
             }
         }
     }
+    }
     // what is left: pad the last group with records no ray passes (R^2 = -inf), then drain the lists
     if (nC > 0 && !out) {
         const int real = nC;
@@ -562,9 +652,14 @@ constexpr int kAffListCap = 1024;  // affine candidates of a wave (LDS); more: e
 template <int PHASE, bool EXC, bool POOL>
 __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const ShadowQ& Qi, const int n, const int base,
                                                    unsigned char* lit, const int lit_cap, const int part, const int parts,
-                                                   unsigned short* alist, ShadowPoolLds* pool, Exec* ex)
+                                                   unsigned short* alist, ShadowPoolLds* pool, ShadowSelLds* lsel, Exec* ex)
 {
     const int c0 = 0, c1 = S.nsb;
+#ifdef RTX_EXPERIMENT_LAMBDA
+    const bool two = false;
+#else
+    const bool two = S.sel2 != 0;  // which member selection this context's frames take (shadow_select; rtx_device.hip)
+#endif
     const int lane = threadIdx.x & 63;
     const int i = base + threadIdx.x;
     const int ii = (i < n) ? i : 0;
@@ -671,11 +766,60 @@ __device__ __forceinline__ void shadow_pass_packet(const SceneDev& S, const Shad
             bool out = __all(done);
             if constexpr (POOL) {
             if (PHASE != 1 && !out) {
-                if (shadow_plain_pool<EXC>(S, P, *pool, o, ld, nld, done ? 1 : 0, part, parts, ex, pk_batches, pk_surv)) done = true;
+                if (shadow_plain_pool<EXC>(S, P, *pool, *lsel, two, o, ld, nld, done ? 1 : 0, part, parts, ex, pk_batches, pk_surv)) done = true;
                 out = __all(done);
             }
             } else {
-            for (int cb = 0; PHASE != 1 && cb < S.sncl && !out; cb += 64) {
+#if !defined(RTX_EXPERIMENT_LAMBDA)
+            // the hierarchy walk of shadow_select, written out (no lambda around the per-lane bool `done`: DESIGN.md 4.5)
+            const int j8 = lane >> 3;
+            for (int cb = 0; two && PHASE != 1 && cb < S.sncl && !out; cb += 64) {
+                const int c = cb + lane;
+                const bool mine = c < S.sncl && (c % parts) == part;
+                const bool cpass = mine && packet_test(P, S.scl[min(c, S.sncl - 1)]);
+                const unsigned long long cm = __ballot(cpass);
+                if (mine) ex_add(ex, EX_PACKET);
+                pk_batches++;
+                if (cm == 0ull) continue;  // wave-uniform
+                const int nc = __popcll(cm);
+                if (cpass) lsel->clist[lanes_below(cm)] = c;
+                lds_fence();
+                for (int c0 = 0; c0 < nc && !out; c0 += 8) {
+                    const bool v1 = c0 + j8 < nc;
+                    const int sid0 = lsel->clist[min(c0 + j8, nc - 1)] * 8 + (lane & 7);
+                    const bool spass = v1 && packet_test_R(P, S.ssubR[sid0]);
+                    if (v1) ex_add(ex, EX_PACKET);
+                    const unsigned long long sm = __ballot(spass);
+                    pk_batches++;
+                    if (sm == 0ull) continue;
+                    const int ns = __popcll(sm);
+                    if (spass) lsel->slist[lanes_below(sm)] = sid0;
+                    lds_fence();
+                    for (int s0 = 0; s0 < ns && !out; s0 += 8) {
+                        const bool v2 = s0 + j8 < ns;
+                        const size_t mi = (size_t)lsel->slist[min(s0 + j8, ns - 1)] * 8 + (lane & 7);
+                        const float4 mb = S.smem[mi];
+                        const int k = v2 ? S.sidx[mi] : -1;
+                        unsigned long long mm = __ballot(k >= 0 && packet_test(P, mb));
+                        if (k >= 0) ex_add(ex, EX_PACKET);
+                        pk_batches++; pk_surv += __popcll(mm);
+                        while (mm) {
+                            const int u = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1;
+                            const float4 br = bcast4(mb, u);
+                            if (!done) ex_add(ex, EX_FILT);
+                            if (!done && filt_front(o, fd, br)) {
+                                if (exact_any(S, __builtin_amdgcn_readlane(k, u), o, ld, nld, ex)) done = true;
+                            }
+                        }
+                        out = __all(done);
+                    }
+                    lds_fence();
+                }
+                lds_fence();
+            }
+#endif
+            for (int cb = 0; !two && PHASE != 1 && cb < S.sncl && !out; cb += 64) {
                 const int c = cb + lane;
                 unsigned long long cm = __ballot(c < S.sncl && (c % parts) == part && packet_test(P, S.scl[min(c, S.sncl - 1)]));
                 if (c < S.sncl && (c % parts) == part) ex_add(ex, EX_PACKET);
@@ -844,12 +988,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(POOL ? R
     const int n = *cnt_in;
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
     __shared__ ShadowPoolLds pool[POOL ? kBlock / 64 : 1];
+    __shared__ ShadowSelLds lsel[kBlock / 64];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
-    shadow_pass_packet<0, EX, POOL>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, nullptr, &pool[POOL ? (threadIdx.x >> 6) : 0], ex);
+    shadow_pass_packet<0, EX, POOL>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, nullptr, &pool[POOL ? (threadIdx.x >> 6) : 0],
+                                    &lsel[threadIdx.x >> 6], ex);
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 
@@ -862,13 +1008,14 @@ __global__ __launch_bounds__(kBlock) void k_shadow_affine(SceneDev S, ShadowQ Qi
     const int parts = (n <= split8) ? 2 * kSplit : (n <= split4) ? kSplit : 1;
     __shared__ unsigned short alist[kBlock / 64][kAffListCap];
     __shared__ ShadowPoolLds pool[(BOTH && POOL) ? kBlock / 64 : 1];  // (PHASE 1 runs no plain stage)
+    __shared__ ShadowSelLds lsel[BOTH ? kBlock / 64 : 1];
     const int base = (blockIdx.x / parts) * kBlock;
     if (base >= n) return;  // block-uniform
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
     shadow_pass_packet<BOTH ? 2 : 1, EX, POOL>(S, Qi, n, base, lit, lit_cap, blockIdx.x % parts, parts, alist[threadIdx.x >> 6],
-                                              &pool[(BOTH && POOL) ? (threadIdx.x >> 6) : 0], ex);
+                                              &pool[(BOTH && POOL) ? (threadIdx.x >> 6) : 0], &lsel[BOTH ? (threadIdx.x >> 6) : 0], ex);
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 
