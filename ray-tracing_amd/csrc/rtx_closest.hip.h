@@ -344,6 +344,22 @@ __device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
     return behind ? -1.0f : rhs * rhs * 1.00001f - h2 * cosE2;
 }
 
+// packet_test for a sphere given as { c, R } (cluster and sub-cluster spheres of the per-ray hierarchy, clR / subR)
+__device__ __forceinline__ bool packet_test_R(const Packet& P, float4 b)
+{
+    float Cx = b.x - P.co.x, Cy = b.y - P.co.y, Cz = b.z - P.co.z;
+    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
+    float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
+    float h2 = (C2 - a * a) - 4e-6f * C2;
+    float Rp = (b.w * 1.00001f + P.rho) * 1.00001f + 1e-20f;
+    float rhs = Rp + a * P.sinT;
+    return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // R = +inf (clusters of never-bounded primitives) passes
+}
+__device__ __forceinline__ int lanes_below_(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 template <bool PREFETCH>
 __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev& L, const int n, const int base, float4* tile, Exec* ex)
 {
@@ -388,6 +404,50 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
                 unsigned long long cm = __ballot(c < c1 && packet_test(P, S.ccl[min(c, c1 - 1)]));
                 if (c < c1) ex_add(ex, EX_PACKET);
                 pk_batches++;
+                if constexpr (!PREFETCH) {
+                    // Frames that fill the chip: two-level member selection (as shadow_select in rtx_shadow.hip.h).  The
+                    // passing clusters are listed and taken eight at a time, lane = (cluster, sub-cluster) against the
+                    // sphere around members 8s .. 8s+7 (csubR); the passing sub-clusters are listed and taken eight at
+                    // a time, lane = (sub-cluster, member).  19 member steps per wave become 2 + 4 on C4.  The lists use
+                    // the wave's candidate-list space, which this walk does not need.
+                    volatile int* clist = reinterpret_cast<volatile int*>(const_cast<unsigned*>(bm) + kSegPrims / 32);
+                    volatile int* slist = clist + 64;
+                    const int j8 = lane >> 3;
+                    if (cm != 0ull) {
+                        const int nc = __popcll(cm);
+                        if ((cm >> lane) & 1ull) clist[lanes_below_(cm)] = c;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (int q0 = 0; q0 < nc; q0 += 8) {
+                            const bool v1 = q0 + j8 < nc;
+                            const int sid0 = clist[min(q0 + j8, nc - 1)] * 8 + (lane & 7);
+                            const bool spass = v1 && packet_test_R(P, S.csubR[sid0]);
+                            if (v1) ex_add(ex, EX_PACKET);
+                            const unsigned long long sm = __ballot(spass);
+                            pk_batches++;
+                            if (sm == 0ull) continue;  // wave-uniform
+                            const int nsb = __popcll(sm);
+                            if (spass) slist[lanes_below_(sm)] = sid0;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            for (int s0 = 0; s0 < nsb; s0 += 8) {
+                                const bool v2 = s0 + j8 < nsb;
+                                const size_t m = (size_t)slist[min(s0 + j8, nsb - 1)] * 8 + (lane & 7);
+                                const float4 mb = S.cmem[m];
+                                const int k = v2 ? S.cidx[m] : -1;
+                                const bool pass = k >= 0 && packet_test(P, mb);
+                                if (k >= 0) ex_add(ex, EX_PACKET);
+                                if (pass) atomicOr(const_cast<unsigned*>(bm) + ((k - p0) >> 5), 1u << ((k - p0) & 31));
+                                pk_batches++; pk_surv += __popcll(__ballot(pass));
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    cm = 0ull;
+                }
                 while (cm) {
                     if constexpr (PREFETCH) {
                         // four clusters' members in flight at a time: one memory round trip per four

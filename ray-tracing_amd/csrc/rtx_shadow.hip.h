@@ -329,18 +329,6 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
 // ------------------------------------------------------------------------------------------------
 struct ShadowSelLds { int clist[64]; int slist[64]; };
 
-// packet_test for a sphere given as { c, R }
-__device__ __forceinline__ bool packet_test_R(const Packet& P, float4 b)
-{
-    float Cx = b.x - P.co.x, Cy = b.y - P.co.y, Cz = b.z - P.co.z;
-    float C2 = Cx * Cx + Cy * Cy + Cz * Cz;
-    float a = fabsf(P.w.x * Cx + P.w.y * Cy + P.w.z * Cz);
-    float h2 = (C2 - a * a) - 4e-6f * C2;
-    float Rp = (b.w * 1.00001f + P.rho) * 1.00001f + 1e-20f;
-    float rhs = Rp + a * P.sinT;
-    return !(h2 * P.cosT2 > rhs * rhs * 1.00001f);     // R = +inf (clusters of never-bounded primitives) passes
-}
-
 template <typename Visit>
 __device__ __forceinline__ int shadow_select(const SceneDev& S, const Packet& P, ShadowSelLds& L, const int part, const int parts,
                                              Exec* ex, int& pk_batches, int& pk_surv, Visit&& visit)
