@@ -698,14 +698,14 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 }
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
                 HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
-                hipLaunchKernelGGL(k_shadow_bin, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
+                hipLaunchKernelGGL(k_shadow_bin, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
                 {
                     const int nb = (c->nbins + 1023) / 1024;
                     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
                     hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
                 }
-                hipLaunchKernelGGL(k_shadow_scatter, dim3(g, c->S.nl), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
+                hipLaunchKernelGGL(k_shadow_scatter, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split4)) * kSplit));
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split8)) * 2 * kSplit));

@@ -86,36 +86,43 @@ __global__ __launch_bounds__(kBlock) void k_shadow_bin(SceneDev S, LevelDev L, c
 {
     const int n = *nnodes;
     const int j = blockIdx.x * kBlock + threadIdx.x;
-    const int li = blockIdx.y;
+    if (blockIdx.x * kBlock >= n) return;  // block-uniform
     const bool live = j < n;
-    int key = -1;
-    if (live) {
-        key = make_shadow_ray(S, L, j, li, G).key;
-        L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
-    }
-    // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key per wave
-    // instead of one per ray.  The groups are formed first (ballots only: leader, size, place in the group),
-    // then every leader issues its atomic in ONE instruction and the wave waits for one round trip, where a
-    // loop of atomic-then-broadcast waited for one per distinct key.
     const int lane = threadIdx.x & 63;
-    int leader_of = lane, prefix = 0, count = 0;
-    unsigned long long pending = __ballot(live);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int k0 = __builtin_amdgcn_readlane(key, leader);
-        const unsigned long long same = __ballot(live && key == k0) & pending;
-        if ((same >> lane) & 1ull) {
-            leader_of = leader;
-            prefix = __popcll(same & ((1ull << lane) - 1ull));
-            count = __popcll(same);
+    const int jj = live ? j : 0;
+    // one thread per HIT, every light in turn: the hit record is read once, not once per light
+    const F3 ip = f3(L.n_px[jj], L.n_py[jj], L.n_pz[jj]);
+    for (int li = 0; li < S.nl; li++) {
+        int key = -1;
+        if (live) {
+            const rtx_light& Lt = S.lights[li];
+            const F3 ldir = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));  // :561-562, as make_shadow_ray
+            key = li * G * G + light_cell(ldir, G);
+            L.lit[li * L.cap + j] = 1;  // until some primitive blocks it
         }
-        pending &= ~same;
+        // Neighbouring hits mostly fall into the same few cells: one returning atomic per distinct key per wave
+        // instead of one per ray.  The groups are formed first (ballots only: leader, size, place in the group),
+        // then every leader issues its atomic in ONE instruction and the wave waits for one round trip, where a
+        // loop of atomic-then-broadcast waited for one per distinct key.
+        int leader_of = lane, prefix = 0, count = 0;
+        unsigned long long pending = __ballot(live);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int k0 = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long same = __ballot(live && key == k0) & pending;
+            if ((same >> lane) & 1ull) {
+                leader_of = leader;
+                prefix = __popcll(same & ((1ull << lane) - 1ull));
+                count = __popcll(same);
+            }
+            pending &= ~same;
+        }
+        int base = 0;
+        if (live && leader_of == lane) base = atomicAdd(hist + key, count);
+        base = __shfl(base, leader_of);
+        const int myrank = base + prefix;
+        if (live) rank[li * n + j] = myrank;
     }
-    int base = 0;
-    if (live && leader_of == lane) base = atomicAdd(hist + key, count);
-    base = __shfl(base, leader_of);
-    const int myrank = base + prefix;
-    if (live) rank[li * n + j] = myrank;
 }
 
 // Exclusive scan of the bin counts in three small launches: per-block scan of 1024 bins, scan of the
@@ -185,21 +192,23 @@ __global__ __launch_bounds__(kBlock) void k_shadow_scatter(SceneDev S, LevelDev 
 {
     const int n = *nnodes;
     const int j = blockIdx.x * kBlock + threadIdx.x;
-    const int li = blockIdx.y;
     if (j >= n) return;
-    ShadowRay r = make_shadow_ray(S, L, j, li, G);
-    const int q = offs[r.key] + rank[li * n + j];
-    Q.a[q] = make_float4(r.o.x, r.o.y, r.o.z, r.ld.x);
-    // the ray's (light, cell) key of the affine table rides along in the record's spare word
-    // (-2: the table does not cover this ray -- further from its light than the table's range, or on top of it)
-    int akey = 0;
-    if (S.aff_dt) {
-        const rtx_light& Lt = S.lights[li];
-        const float lx = Lt.point.x - r.o.x, ly = Lt.point.y - r.o.y, lz = Lt.point.z - r.o.z;
-        const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
-        akey = (dist <= S.aff_dt[li] && dist >= 1e-2f) ? li * S.aff_G * S.aff_G + light_cell(r.ld, S.aff_G) : -2;
+    // one thread per HIT, every light in turn (the hit record is read once)
+    for (int li = 0; li < S.nl; li++) {
+        ShadowRay r = make_shadow_ray(S, L, j, li, G);
+        const int q = offs[r.key] + rank[li * n + j];
+        Q.a[q] = make_float4(r.o.x, r.o.y, r.o.z, r.ld.x);
+        // the ray's (light, cell) key of the affine table rides along in the record's spare word
+        // (-2: the table does not cover this ray -- further from its light than the table's range, or on top of it)
+        int akey = 0;
+        if (S.aff_dt) {
+            const rtx_light& Lt = S.lights[li];
+            const float lx = Lt.point.x - r.o.x, ly = Lt.point.y - r.o.y, lz = Lt.point.z - r.o.z;
+            const float dist = fsqrt(lx * lx + ly * ly + lz * lz) * 1.00001f;
+            akey = (dist <= S.aff_dt[li] && dist >= 1e-2f) ? li * S.aff_G * S.aff_G + light_cell(r.ld, S.aff_G) : -2;
+        }
+        Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), __int_as_float(akey));
     }
-    Q.b[q] = make_float4(r.ld.y, r.ld.z, __int_as_float(li * L.cap + j), __int_as_float(akey));
 }
 
 // Affine spheres.  The reference maps only the
