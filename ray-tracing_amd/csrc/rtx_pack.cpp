@@ -62,37 +62,40 @@ rtx_xmatrix inverse_matrix(const rtx_xmatrix& m, bool* singular)
 
 namespace {
 
-inline uint32_t spread10(uint32_t v)
+struct Item { double c[3]; double R; int32_t slot; };
+
+// items [lo, hi) -> k-d order with leaves of `leaf` consecutive items (see emit_clusters)
+void kd_order(std::vector<Item>& items, size_t lo, size_t hi, size_t leaf)
 {
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+    while (hi - lo > leaf) {
+        double bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = lo; i < hi; i++)
+            for (int a = 0; a < 3; a++) { bl[a] = std::min(bl[a], items[i].c[a]); bh[a] = std::max(bh[a], items[i].c[a]); }
+        int ax = 0;
+        for (int a = 1; a < 3; a++) if (bh[a] - bl[a] > bh[ax] - bl[ax]) ax = a;
+        const size_t leaves = (hi - lo + leaf - 1) / leaf;
+        const size_t mid = lo + (leaves / 2) * leaf;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, [ax](const Item& a, const Item& b) {
+            return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.slot < b.slot);
+        });
+        kd_order(items, lo, mid, leaf);
+        lo = mid;
+    }
 }
 
-struct Item { double c[3]; double R; uint32_t key; int32_t slot; };
-
-// one group of items -> clusters of <= 64 consecutive items in Morton order of their centres
+// one group of items -> clusters of <= 64 consecutive items in k-d order of their centres
 void emit_clusters(std::vector<Item>& items, bool bounded, const std::vector<BoundSphere>& rec,
                    const std::vector<int32_t>& ids, ClusterSet& out)
 {
     if (items.empty()) return;
     if (bounded) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (const Item& it : items)
-            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], it.c[a]); hi[a] = std::max(hi[a], it.c[a]); }
-        for (Item& it : items) {
-            uint32_t q[3];
-            for (int a = 0; a < 3; a++) {
-                double e = hi[a] - lo[a];
-                double f = e > 0 ? (it.c[a] - lo[a]) / e : 0.0;
-                q[a] = (uint32_t)std::min(1023.0, std::max(0.0, f * 1024.0));
-            }
-            it.key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-        }
-        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+        // k-d order: the run is cut at the median of its widest axis into two runs whose sizes are multiples of the
+        // leaf size, down to leaves of 64 (clusters: every cluster but the last is full), then every cluster again
+        // down to leaves of 8 (its sub-clusters).  Cells of a k-d partition are compact where runs of a space-filling
+        // curve straddle its jumps: fewer cluster and sub-cluster spheres pass a ray or a packet.
+        kd_order(items, 0, items.size(), kClusterSize);
+        for (size_t i0 = 0; i0 < items.size(); i0 += kClusterSize)
+            kd_order(items, i0, std::min(items.size(), i0 + kClusterSize), 8);
     }
     const float inf = std::numeric_limits<float>::infinity();
     // sphere around items [j0, j1): centre rounded to binary32 FIRST, radius measured from the rounded
@@ -158,7 +161,7 @@ void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32
                 if (cls && ((*cls)[i] != 0) != (pass == 1)) continue;
                 const BoundSphere& b = rec[i];
                 if (b.neg_r2 == std::numeric_limits<float>::infinity()) continue;  // can never pass: in no cluster
-                Item it = {{b.cx, b.cy, b.cz}, 0.0, 0u, (int32_t)i};
+                Item it = {{b.cx, b.cy, b.cz}, 0.0, (int32_t)i};
                 bool ok = std::isfinite(b.cx) && std::isfinite(b.cy) && std::isfinite(b.cz) && std::isfinite(b.neg_r2) && b.neg_r2 <= 0.0f;
                 if (!ok) { unb.push_back(it); continue; }
                 it.R = std::sqrt(-(double)b.neg_r2);
