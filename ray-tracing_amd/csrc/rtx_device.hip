@@ -187,7 +187,6 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->device = dev;
     c->params = *params;
     c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
-    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
     if (const char* e4 = std::getenv("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
     if (const char* e8 = std::getenv("RTX_SPLIT8")) c->split8 = std::atoi(e8);
     c->width = params->width;
@@ -544,6 +543,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     // forces it (A/B aid; same image).
     c->S.sel2 = ((int64_t)rows * W >= ((int64_t)1 << 22)) ? 1 : 0;
     if (const char* e2 = std::getenv("RTX_TWO_LEVEL")) c->S.sel2 = std::atoi(e2) ? 1 : 0;
+    // Generation 0's shadow rays take the walk when they fill the chip and the pooled stages when they do not (chunks of
+    // <= 3 * 2^20 primary rays: a rank's share of 4 or 8 of the 4K frame, halo rows included; measured 1.20 -> 1.04 ms for a rank of 8, 1.59 -> 1.55
+    // for a rank of 4, 2.59 -> 2.67 for a rank of 2, 4.03 -> 4.18 for the whole frame).
+    if ((int64_t)rows * W <= ((int64_t)3 << 20)) c->pool_from = 0;
+    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
     if ((rc = alloc_levels(caps, true))) return rc;
     {   // shadow-ray queues: the largest generation's hits x lights
         size_t mx = 0;
