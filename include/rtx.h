@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 0x00030100u
+#define RTX_ABI_VERSION 0x00030200u
 
 /* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
  * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
@@ -266,7 +266,7 @@ int  rtx_band_rows(int32_t height, int32_t nranks, int32_t rank, int32_t band_ro
                    int32_t* rows_out, int32_t capacity);
 
 /* ---- diagnostics (pure host functions; no counterpart in the reference) -----------------------
- * All three validate the scene view like rtx_context_create, return the number of records (or a negative
+ * All of them validate the scene view like rtx_context_create, return the number of records (or a negative
  * RTX_E_* code), accept a NULL output pointer to query that number, and fail with RTX_E_INVALID_ARG when
  * `capacity` (in records) is smaller.
  *
@@ -284,6 +284,19 @@ int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t cap
  * |P - v|_1 <= Q whose barycentric coordinate a1.(P - v), a2.(P - v) or 1 - both is below -m (-2m for the
  * third).  Q = -1: never rejected.  Exported so the CPU suite can check that bound against the reference's test. */
 int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capacity);
+
+/* The cluster hierarchy the traversal kernels walk (rtx_pack.cpp: build_clusters): which = 0, the closest-hit set over
+ * the records of rtx_filter_records; which = 1, the shadow set (plain spheres and triangles).  Returns the number of
+ * clusters ncl; with non-NULL outputs (capacity in clusters, >= ncl) it fills
+ *   cluster4 [ncl * 4]       { c.x, c.y, c.z, R }   the cluster spheres (R = +inf: always passes),
+ *   sub4     [ncl * 8 * 4]   { c, R }               the spheres around members 8s .. 8s+7 of every cluster,
+ *   member4  [ncl * 64 * 4]  { c, -R^2 }            the members' own filter records, padding = { 0, 0, 0, +inf },
+ *   index    [ncl * 64]      primitive index of every member slot (sphere i | nspheres + triangle i | ...), -1 = padding.
+ * Any of the four may be NULL.  Exported so the CPU suite can check what the culling argument rests on: every primitive
+ * whose record can pass sits in exactly one slot, and every member's sphere lies inside its sub-cluster's and its
+ * cluster's.  No counterpart in the reference. */
+int  rtx_cluster_records(const rtx_scene* scene, int32_t which, float* cluster4, float* sub4, float* member4,
+                         int32_t* index, int32_t capacity);
 
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),

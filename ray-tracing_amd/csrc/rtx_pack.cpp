@@ -465,6 +465,27 @@ extern "C" int rtx_affine_shadow_records(const rtx_scene* scene, float* out16, i
     RTX_PACK_CATCH
 }
 
+extern "C" int rtx_cluster_records(const rtx_scene* scene, int32_t which, float* cluster4, float* sub4, float* member4,
+                                   int32_t* index, int32_t capacity)
+{
+    int rc = rtx::validate_scene(scene);
+    if (rc) return rc;
+    if (which != 0 && which != 1) return RTX_E_INVALID_ARG;
+    RTX_PACK_TRY
+    rtx::PackedScene P;
+    rtx::pack_scene(*scene, 1, 1, P, 0u);
+    const rtx::ClusterSet& cs = which ? P.sc : P.cc;
+    const int ncl = (int)cs.clR.size();
+    if ((cluster4 || sub4 || member4 || index) && capacity < ncl) return RTX_E_INVALID_ARG;
+    static_assert(sizeof(rtx::BoundSphere) == 16, "4 floats");
+    if (cluster4 && ncl) std::memcpy(cluster4, cs.clR.data(), (size_t)ncl * 16);
+    if (sub4 && ncl) std::memcpy(sub4, cs.subR.data(), (size_t)ncl * 8 * 16);
+    if (member4 && ncl) std::memcpy(member4, cs.mem.data(), (size_t)ncl * rtx::kClusterSize * 16);
+    if (index && ncl) std::memcpy(index, cs.idx.data(), (size_t)ncl * rtx::kClusterSize * sizeof(int32_t));
+    return ncl;
+    RTX_PACK_CATCH
+}
+
 extern "C" int rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capacity)
 {
     int rc = rtx::validate_scene(scene);

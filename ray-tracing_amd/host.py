@@ -136,6 +136,7 @@ SYMBOLS = {
     "rtx_filter_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
+    "rtx_cluster_records": (C.c_int, [C.POINTER(SceneView), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_load_legacy": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
@@ -265,6 +266,18 @@ def triangle_edge_records(scene):
     out = np.zeros((scene.view.ntriangles, 8), dtype=np.float32)
     _check(lib().rtx_triangle_edge_records(scene.ptr, out.ctypes.data, scene.view.ntriangles), "rtx_triangle_edge_records")
     return out
+
+
+def cluster_records(scene, which=0):
+    """(cluster[ncl,4], sub[ncl,8,4], member[ncl,64,4], index[ncl,64]): the hierarchy the traversal kernels walk
+    (rtx_cluster_records); which = 0 closest hit, 1 shadow rays."""
+    n = _check(lib().rtx_cluster_records(scene.ptr, which, None, None, None, None, 0), "rtx_cluster_records")
+    cl = np.zeros((n, 4), dtype=np.float32); sub = np.zeros((n, 8, 4), dtype=np.float32)
+    mem = np.zeros((n, 64, 4), dtype=np.float32); idx = np.zeros((n, 64), dtype=np.int32)
+    if n:
+        _check(lib().rtx_cluster_records(scene.ptr, which, cl.ctypes.data, sub.ctypes.data, mem.ctypes.data, idx.ctypes.data, n),
+               "rtx_cluster_records")
+    return cl, sub, mem, idx
 
 
 def affine_shadow_records(scene):
