@@ -110,6 +110,23 @@ struct rtx_context {
     int main_from = 1 << 30;
     int split4 = kSplitRays, split8 = kSplitRays8;  // shadow generations up to this many rays: 4 / 8 workgroups per 256 rays
     std::vector<hipEvent_t> ev_fork, ev_pass;  // per generation: set-up done (main stream), shadow pass done (side stream)
+    // k_closest_lanes' own cluster set (PackedScene::pc) for scenes of more than one segment; has_pc = false: S's own
+    struct LanesSet {
+        bool has_pc = false;
+        const float4 *cmem = nullptr, *cclR = nullptr, *csubR = nullptr;
+        const int *cidx = nullptr, *cseg = nullptr, *corder = nullptr;
+        int cnfirst = 0;
+    } lanes;
+    SceneDev lanes_scene() const
+    {
+        SceneDev SL = S;
+        if (lanes.has_pc) {
+            SL.cmem = lanes.cmem; SL.cclR = lanes.cclR; SL.csubR = lanes.csubR;
+            SL.cidx = lanes.cidx; SL.cseg = lanes.cseg; SL.corder = lanes.corder;
+            SL.cnseg = 1; SL.cnfirst = lanes.cnfirst;
+        }
+        return SL;
+    }
     size_t qpad = 0;                        // slots the 64-alignment of the shadow bin groups can add to a queue
     int* d_scnt = nullptr;                  // [nchunks*levels] slots (rays + alignment padding) of each generation's shadow queue
     int nframe_chunks = 0;
@@ -292,6 +309,19 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->upload(&q, P.cc.order))) return rc;
             c->S.corder = q;
             c->S.cnfirst = P.cc.nfirst;
+            if (!P.pc.clR.empty()) {
+                if ((rc = up4(P.pc.mem, &c->lanes.cmem))) return rc;
+                if ((rc = up4(P.pc.clR, &c->lanes.cclR))) return rc;
+                if ((rc = up4(P.pc.subR, &c->lanes.csubR))) return rc;
+                if ((rc = c->upload(&q, P.pc.idx))) return rc;
+                c->lanes.cidx = q;
+                if ((rc = c->upload(&q, P.pc.seg_first))) return rc;
+                c->lanes.cseg = q;
+                if ((rc = c->upload(&q, P.pc.order))) return rc;
+                c->lanes.corder = q;
+                c->lanes.cnfirst = P.pc.nfirst;
+                c->lanes.has_pc = true;
+            }
             if ((rc = up4(P.sc.cl, &c->S.scl))) return rc;
             if ((rc = up4(P.sc.mem, &c->S.smem))) return rc;
             if ((rc = up4(P.sc.subR, &c->S.ssubR))) return rc;
@@ -614,7 +644,7 @@ static int calibrate_counts(rtx_context* c, int* d_blk)
             const int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             if (!spawn) break;  // the last generation spawns nothing: its count is already known
             const unsigned g = grid_for(live_cap);
-            if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->S, Lk, rays + k);
+            if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
             else if (live_cap < kPrefetchRays) hipLaunchKernelGGL((k_closest_f<true, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             else hipLaunchKernelGGL((k_closest_f<false, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, rays + k + 1, spawn, c->d_overflow);
@@ -667,8 +697,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) {
                 const dim3 gl(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64)));
-                if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->S, Lk, rays + k);
-                else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->S, Lk, rays + k);
+                if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
+                else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
             }
             else if (live_cap < kPrefetchRays) {
                 if (exec) hipLaunchKernelGGL((k_closest_f<true, true>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);

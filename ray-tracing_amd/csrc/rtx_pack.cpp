@@ -375,6 +375,7 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P, uint
         std::vector<uint8_t> cls(P.bounds.size(), 0);
         for (size_t i = 0; i < P.sph_xf.size(); i++) cls[i] = P.sph_xf[i] ? 1 : 0;
         build_clusters(P.bounds, all, kSegPrims, &cls, P.cc);
+        if (P.cc.seg_first.size() > 2) build_clusters(P.bounds, all, 0, &cls, P.pc);
         build_clusters(P.sbounds, P.sorder, 0, nullptr, P.sc);
     }
 

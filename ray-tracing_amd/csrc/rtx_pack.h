@@ -79,6 +79,10 @@ void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32
 struct PackedScene {
     ClusterSet cc;                            // closest-hit clusters over `bounds`, segmented
     ClusterSet sc;                            // shadow clusters over `sbounds`, one segment
+    // The per-ray traversal (k_closest_lanes) keeps the best (t, index) pair and needs no file order: scenes of more than
+    // one segment get a set of their own for it, built over ALL records at once (seven overlapping hierarchies over 100,000
+    // triangles otherwise, each cluster seven times the volume).  Empty when cc has one segment (cc serves both).
+    ClusterSet pc;
     std::vector<AffineShadowRec> aff_shadow;  // one per affine sphere, file order
     // Shadow rays are any-hit: the order primitives are tried in cannot change the result, only how
     // soon a blocked ray stops.  sbounds = filter records of the shadow casters (spheres and triangles; polygons
