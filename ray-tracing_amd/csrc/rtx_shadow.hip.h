@@ -42,6 +42,7 @@ struct ShadowQ { float4 *a, *b; };
 // octahedral G x G map of the direction, cells in Morton order -- before the passes: a wave then
 // holds 64 rays inside a cone of a degree or so with its apex AT the light, the packet test keeps a
 // few dozen of the 10,000 primitives, and the 64 rays tend to be blocked by the same primitive.
+// (8 bits per axis: the direction maps hold at most 256 x 256 cells -- rtx_device.hip: binG and the affine table's G)
 __device__ __forceinline__ unsigned morton8(unsigned x)
 {
     x &= 0xffu;
