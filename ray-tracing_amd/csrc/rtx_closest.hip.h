@@ -838,11 +838,25 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     };
 
     const int ncl = S.cseg[S.cnseg];
+    static_assert(kPoolQ % kSuperRun == 0, "a round of stage A is a whole number of ClusterSet::supR runs");
+    const int nsup0 = (S.cnfirst + kSuperRun - 1) / kSuperRun;
     for (int phase = 0; phase < 2; phase++) {
         const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
         front = phase == 1;
         for (int cb = cbeg; cb < cend; cb += kPoolQ) {
             const int ce = min(kPoolQ, cend - cb);
+            // ---- the spheres around the round's runs of 8 clusters first: a wave none of whose rays can pass one
+            //      skips the round ----
+            {
+                const int s0 = (phase ? nsup0 : 0) + (cb - cbeg) / kSuperRun, sn = (ce + kSuperRun - 1) / kSuperRun;
+                bool spass = aabn;
+                for (int v = 0; v < sn; v++) {
+                    const float4 sup = S.csupR[s0 + v];
+                    if (alive && !aabn) ex_add(ex, EX_CONE);
+                    spass = spass || !(cone_slack(ao, an, sup) < 0.0f);
+                }
+                if (!__any(alive && spass)) continue;  // wave-uniform
+            }
             // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
             if (lane < ce) {
                 const int c = S.corder[cb + lane];

@@ -113,7 +113,7 @@ struct rtx_context {
     // k_closest_lanes' own cluster set (PackedScene::pc) for scenes of more than one segment; has_pc = false: S's own
     struct LanesSet {
         bool has_pc = false;
-        const float4 *cmem = nullptr, *cclR = nullptr, *csubR = nullptr;
+        const float4 *cmem = nullptr, *cclR = nullptr, *csubR = nullptr, *csupR = nullptr;
         const int *cidx = nullptr, *cseg = nullptr, *corder = nullptr;
         int cnfirst = 0;
     } lanes;
@@ -121,7 +121,7 @@ struct rtx_context {
     {
         SceneDev SL = S;
         if (lanes.has_pc) {
-            SL.cmem = lanes.cmem; SL.cclR = lanes.cclR; SL.csubR = lanes.csubR;
+            SL.cmem = lanes.cmem; SL.cclR = lanes.cclR; SL.csubR = lanes.csubR; SL.csupR = lanes.csupR;
             SL.cidx = lanes.cidx; SL.cseg = lanes.cseg; SL.corder = lanes.corder;
             SL.cnseg = 1; SL.cnfirst = lanes.cnfirst;
         }
@@ -306,6 +306,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.cnseg = (int)P.cc.seg_first.size() - 1;
             if ((rc = up4(P.cc.clR, &c->S.cclR))) return rc;
             if ((rc = up4(P.cc.subR, &c->S.csubR))) return rc;
+            if ((rc = up4(P.cc.supR, &c->S.csupR))) return rc;
             if ((rc = c->upload(&q, P.cc.order))) return rc;
             c->S.corder = q;
             c->S.cnfirst = P.cc.nfirst;
@@ -313,6 +314,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 if ((rc = up4(P.pc.mem, &c->lanes.cmem))) return rc;
                 if ((rc = up4(P.pc.clR, &c->lanes.cclR))) return rc;
                 if ((rc = up4(P.pc.subR, &c->lanes.csubR))) return rc;
+                if ((rc = up4(P.pc.supR, &c->lanes.csupR))) return rc;
                 if ((rc = c->upload(&q, P.pc.idx))) return rc;
                 c->lanes.cidx = q;
                 if ((rc = c->upload(&q, P.pc.seg_first))) return rc;

@@ -205,6 +205,37 @@ void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32
         if (pass == 1) out.nfirst = (int32_t)out.order.size();
     }
     out.seg_first.push_back((int32_t)out.cl.size());
+    // spheres around the rounds of the per-ray traversal
+    const float inf = std::numeric_limits<float>::infinity();
+    const int32_t ncl = (int32_t)out.order.size();
+    for (int phase = 0; phase < 2; phase++) {
+        const int32_t beg = phase ? out.nfirst : 0, end = phase ? ncl : out.nfirst;
+        for (int32_t cb = beg; cb < end; cb += kSuperRun) {
+            const int32_t ce = std::min(end, cb + kSuperRun);
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool bounded = true;
+            for (int32_t u = cb; u < ce; u++) {
+                const BoundSphere& b = out.clR[out.order[u]];
+                const float cc[3] = {b.cx, b.cy, b.cz};
+                if (!(b.neg_r2 < 1e15f)) { bounded = false; break; }  // +inf or NaN radius
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)cc[a] - b.neg_r2); hi[a] = std::max(hi[a], (double)cc[a] + b.neg_r2); }
+            }
+            BoundSphere sp = {0.0f, 0.0f, 0.0f, inf};
+            if (bounded) {
+                const float cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2]))};
+                double R = 0.0;
+                for (int32_t u = cb; u < ce; u++) {
+                    const BoundSphere& b = out.clR[out.order[u]];
+                    const double dx = b.cx - cf[0], dy = b.cy - cf[1], dz = b.cz - cf[2];
+                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)b.neg_r2);
+                }
+                const float Rf = std::nextafter((float)(R * (1.0 + 1e-6)), inf);
+                if (std::isfinite(Rf) && Rf < 1e15f && std::isfinite(cf[0]) && std::isfinite(cf[1]) && std::isfinite(cf[2]))
+                    sp = {cf[0], cf[1], cf[2], Rf};
+            }
+            out.supR.push_back(sp);
+        }
+    }
 }
 
 void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P, uint32_t flags)

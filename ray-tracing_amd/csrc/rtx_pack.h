@@ -57,6 +57,7 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
 // per segment of kSegPrims consecutive primitives and only mark bits in a per-wave bitmap that is then
 // walked in index order; shadow rays are any-hit and test members as they come.
 constexpr int kClusterSize = 64;
+constexpr int kSuperRun = 8;     // divides closest_pool's kPoolQ (8 or 32; static_assert there)
 constexpr int kSegPrims = 1 << 14;
 struct ClusterSet {
     std::vector<BoundSphere> cl;        // [ncl]
@@ -71,6 +72,10 @@ struct ClusterSet {
     // the 4th component (+inf: always passes); clR [ncl] = the cluster spheres, subR [ncl * 8] = spheres
     // around members 8g .. 8g+7 of each cluster
     std::vector<BoundSphere> clR, subR;
+    // supR: { c, R } around every run of kSuperRun consecutive entries of `order`, the affine-first part and the rest
+    // counted apart (closest_pool, stage A takes one or four runs a round): a wave none of whose rays passes a round's
+    // spheres skips the round.  Consecutive clusters are neighbours in k-d order, so the runs are compact.
+    std::vector<BoundSphere> supR;
 };
 // cls (optional, per record): records with a non-zero class are clustered apart from the others
 void build_clusters(const std::vector<BoundSphere>& rec, const std::vector<int32_t>& ids, int seg_prims,
