@@ -411,6 +411,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     const double fan = c->fanout >= 2 ? 2.0 : 1.0;
     const size_t nl1 = (size_t)std::max(c->S.nl, 1);
     c->binG = 256;
+    // 512 x 512 cells per light for frames of >= 24 M primary rays (8K): a cell of the 256 map then holds several waves of
+    // rays, each as wide as the cell; with the finer map the packets are half as wide (C5: 119.5 -> 107.6 ms; the 4K
+    // frame has 126 rays per cell of the 256 map and loses with the finer one: 4.02 -> 4.10 ms)
+    if ((int64_t)ntrace * W >= (int64_t)24 << 20) c->binG = 512;
+    if (const char* bg = std::getenv("RTX_BIN_G")) c->binG = std::max(8, std::min(1024, std::atoi(bg)));  // A/B aid (same image)
     while (nl1 * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
     c->nbins = (int)nl1 * c->binG * c->binG;
     c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
@@ -884,7 +889,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G"})  // the A/B aids context creation reads
         if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }

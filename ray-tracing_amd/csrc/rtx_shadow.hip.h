@@ -42,13 +42,14 @@ struct ShadowQ { float4 *a, *b; };
 // octahedral G x G map of the direction, cells in Morton order -- before the passes: a wave then
 // holds 64 rays inside a cone of a degree or so with its apex AT the light, the packet test keeps a
 // few dozen of the 10,000 primitives, and the 64 rays tend to be blocked by the same primitive.
-// (8 bits per axis: the direction maps hold at most 256 x 256 cells -- rtx_device.hip: binG and the affine table's G)
-__device__ __forceinline__ unsigned morton8(unsigned x)
+// (12 bits per axis: direction maps of up to 4096 x 4096 cells; rtx_device.hip uses 256 or 512 for the sort, 256 for the affine table)
+__device__ __forceinline__ unsigned morton12(unsigned x)
 {
-    x &= 0xffu;
-    x = (x | (x << 4)) & 0x0f0fu;
-    x = (x | (x << 2)) & 0x3333u;
-    x = (x | (x << 1)) & 0x5555u;
+    x &= 0xfffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
     return x;
 }
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ int light_cell(F3 v, int G)
     // fminf/fmaxf drop NaN operands, so a NaN direction lands in cell 0
     int cx = (int)fminf(fmaxf((px * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
     int cy = (int)fminf(fmaxf((py * 0.5f + 0.5f) * (float)G, 0.0f), (float)(G - 1));
-    return (int)(morton8((unsigned)cx) | (morton8((unsigned)cy) << 1));
+    return (int)(morton12((unsigned)cx) | (morton12((unsigned)cy) << 1));
 }
 
 
@@ -287,12 +288,13 @@ __device__ __forceinline__ bool affine_strip_pass(const StripPacket& K, float4 m
 //     hit point, the ray from a point 1e-4 off it (raytracing.cpp:568).
 // Built once per context; the pass ORs the masks of the cells its rays fall into and runs the strip test of its
 // own, tighter packet on those spheres only.
-__device__ __forceinline__ unsigned demorton8(unsigned x)
+__device__ __forceinline__ unsigned demorton12(unsigned x)
 {
-    x &= 0x5555u;
-    x = (x | (x >> 1)) & 0x3333u;
-    x = (x | (x >> 2)) & 0x0f0fu;
-    x = (x | (x >> 4)) & 0x00ffu;
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x00000fffu;
     return x;
 }
 
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(kBlock) void k_affine_cells(SceneDev S, int G, cons
     const int lane = threadIdx.x & 63;
     if (cell >= S.nl * G * G) return;
     const int li = cell / (G * G), m = cell % (G * G);
-    const float qx = ((float)demorton8((unsigned)m) + 0.5f) / (float)G * 2.0f - 1.0f;
-    const float qy = ((float)demorton8((unsigned)m >> 1) + 0.5f) / (float)G * 2.0f - 1.0f;
+    const float qx = ((float)demorton12((unsigned)m) + 0.5f) / (float)G * 2.0f - 1.0f;
+    const float qy = ((float)demorton12((unsigned)m >> 1) + 0.5f) / (float)G * 2.0f - 1.0f;
     F3 v;
     if (fabsf(qx) + fabsf(qy) <= 1.0f) v = f3(qx, qy, 1.0f - fabsf(qx) - fabsf(qy));
     else v = f3((1.0f - fabsf(qy)) * (qx >= 0.0f ? 1.0f : -1.0f), (1.0f - fabsf(qx)) * (qy >= 0.0f ? 1.0f : -1.0f), 1.0f - fabsf(qx) - fabsf(qy));
