@@ -411,14 +411,18 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     const double fan = c->fanout >= 2 ? 2.0 : 1.0;
     const size_t nl1 = (size_t)std::max(c->S.nl, 1);
     c->binG = 256;
-    // 512 x 512 cells per light for frames of >= 24 M primary rays (8K): a cell of the 256 map then holds several waves of
-    // rays, each as wide as the cell; with the finer map the packets are half as wide (C5: 119.5 -> 107.6 ms; the 4K
-    // frame has 126 rays per cell of the 256 map and loses with the finer one: 4.02 -> 4.10 ms)
-    // ... and for scenes of >= 32,768 shadow casters at any frame size: the denser the scene, the more a narrower packet
-    // saves (a rank of 2 / 4 of C5: 68.4 -> 60.7 / 34.6 -> 30.8 ms)
-    if ((int64_t)ntrace * W >= (int64_t)24 << 20 || c->S.nsb >= 32768) c->binG = 512;
-    if (const char* bg = std::getenv("RTX_BIN_G")) c->binG = std::max(8, std::min(1024, std::atoi(bg)));  // A/B aid (same image)
-    while (nl1 * c->binG * c->binG > ((size_t)1 << 22) && c->binG > 8) c->binG /= 2;
+    // Finer maps where a cell of the 256 map would hold several waves of rays, each as wide as the cell, and where the
+    // scene is dense (the denser the scene, the more a narrower packet saves): 512 x 512 cells per light for frames of
+    // >= 24 M primary rays (8K), 1024 x 1024 in scenes of >= 32,768 shadow casters at any frame size.  Measured on C5
+    // (100,000 triangles, 16 lights): 119.5 ms with 256, 106.2 with 512, 99.0 with 1024, 102.7 with 2048; a rank of 8 of
+    // it 22.5 / 18.8 / 16.3 ms.  The 4K frame of C4 (10,000 primitives) has 126 rays per cell of the 256 map and loses
+    // with a finer one (4.02 -> 4.10 ms).  The block of the no-allocation entry point keeps 256 (the histograms' size).
+    if (!c->arena) {
+        if ((int64_t)ntrace * W >= (int64_t)24 << 20) c->binG = 512;
+        if (c->S.nsb >= 32768) c->binG = 1024;
+    }
+    if (const char* bg = std::getenv("RTX_BIN_G")) c->binG = std::max(8, std::min(4096, std::atoi(bg)));  // A/B aid (same image)
+    while (nl1 * c->binG * c->binG > ((size_t)1 << 24) && c->binG > 8) c->binG /= 2;
     c->nbins = (int)nl1 * c->binG * c->binG;
     c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
     // ---- ray-queue capacities -----------------------------------------------------------------------------------

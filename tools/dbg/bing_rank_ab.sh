@@ -2,7 +2,7 @@
 # A/B of RTX_BIN_G on one rank's share of the C5 frame (N = 2, 4; bands of 30 rows)
 cd $GRAFT_REPO_ROOT
 for N in ${NS:-2 4}; do
-for g in 256 512; do
+for g in ${GS:-256 512}; do
   echo -n "N=$N binG=$g  "
   RTX_BIN_G=$g timeout -k 10 280 python3 -c "
 import sys, os, tempfile
