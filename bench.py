@@ -43,6 +43,9 @@ FLOP_PER_TEST = (20.0, 65.0, 76.0, 13.0)  # sphere, affine sphere,
 EXEC_FLOPS = {"packet": 28.0, "cone": 25.0, "filt": 16.0, "afilt": 39.0, "strip": 150.0,
               "sph": 20.0, "sphx": 65.0, "tri_early": 13.0, "tri_cull": 13.0, "tri_edge": 38.0, "tri_full": 76.0,
               "poly": 30.0, "packets_built": 0.0, "rays": 0.0}
+# the kinds that ARE the reference's own tests; tri_edge is credited with the 13 FLOPs of the plane
+# intersection it shares with intersecttriangle (raytracing.cpp:338-350), not with the edge filter's 25
+REFERENCE_KINDS = {"sph": 20.0, "sphx": 65.0, "tri_early": 13.0, "tri_cull": 13.0, "tri_edge": 13.0, "tri_full": 76.0, "poly": 30.0}
 PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
 PEAK_FP32_NOFMA_TFLOPS = 78.65            # contraction is off for parity: one FLOP per lane-op
 
@@ -118,14 +121,18 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
         fl = sum(ex[kn][kd] * EXEC_FLOPS[kd] for kd in ex[kn])
         t, n = ms[kn]
         ach = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        rfl = sum(ex[kn][kd] * REFERENCE_KINDS.get(kd, 0.0) for kd in ex[kn])
         per[kn] = {"ms_serial": t, "launches": n, "executed_flops": fl, "achieved": ach, "frac": ach / PEAK_FP32_TFLOPS,
-                   "frac_no_fma": ach / PEAK_FP32_NOFMA_TFLOPS, "executed_tests": {k: v for k, v in ex[kn].items() if v}}
+                   "frac_no_fma": ach / PEAK_FP32_NOFMA_TFLOPS, "reference_test_flops": rfl,
+                   "useful_frac": (rfl / (t * 1e-3) / 1e12 / PEAK_FP32_TFLOPS) if t > 0 else 0.0,
+                   "executed_tests": {k: v for k, v in ex[kn].items() if v}}
     dom = max(per, key=lambda k: per[k]["ms_serial"])
     d = per[dom]
     tot_fl = sum(v["executed_flops"] for v in per.values())
     roof.update(kernel=dom, achieved=d["achieved"], frac=d["frac"], frac_no_fma=d["frac_no_fma"],
                 launches_per_frame=d["launches"], avg_launch_ms=d["ms_serial"] / max(d["launches"], 1),
                 executed_flops_per_launch=d["executed_flops"] / max(d["launches"], 1),
+                reference_test_flops=d["reference_test_flops"], useful_frac=d["useful_frac"],
                 per_kernel=per,
                 frame={"ms_serial": ss.ms_total, "ms_overlapped": st_timed.ms_total, "executed_flops": tot_fl,
                        "achieved": tot_fl / (st_timed.ms_total * 1e-3) / 1e12,
@@ -134,8 +141,10 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
                 note="achieved = FLOPs of the tests this kernel EXECUTES (rtx_stats.exec_counts of a counting frame x flops_per_test) "
                      "/ its summed launch time in a serial frame (RTX_F_SERIAL, HIP events; nothing overlaps); frame.* = the three "
                      "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.  "
-                     "k_shadow_pass = one timed bracket per generation: the traversal kernel k_shadow_pass plus the affine-sphere kernel "
-                     "k_shadow_affine behind it (or the fused k_shadow_affine<.,true> of a thin generation).")
+                     "reference_test_flops / useful_frac = the same with only the reference's own tests credited (SURVEY.md 8d: sphere, "
+                     "affine sphere, triangle; none of the culling tests in front of them).  "
+                     "k_shadow_pass = one timed bracket per generation: the table walk k_shadow_cells (plain spheres and triangles) plus "
+                     "the affine-sphere kernel k_shadow_affine behind it.")
     # (c) what the reference's brute-force loops would execute for the same rays, and the exact-only kernels' own fraction
     bw, bh = (W, H) if args.workload != "c5" else (W // 16, H // 16)   # C5 brute force at full size is minutes per frame
     import rtxamd as rt_
@@ -171,7 +180,7 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
         src, rows = pmc_summary(args.workload)
         frames, tot_valu = None, 0.0
         # the timed bracket of a shadow generation holds the traversal kernel AND the affine-sphere kernel behind it
-        group = ("k_shadow_pass", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
+        group = ("k_shadow_pass", "k_shadow_cells", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
         acc = {}
         for row in rows:
             name = row["kernel"].replace("rtx::", "")
@@ -353,7 +362,9 @@ def main():
             "metric": {"c4": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5",
                        "c4r": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5, 5% refractive variant",
                        "c5": "Mrays/sec (primary+secondary+shadow rays traced) at 8K depth 8"}[args.workload],
-            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Mrays/s",
+            "value_primary_secondary": float((rays[0] + rays[1]).item()) * args.steps / dt / 1e6,   # BASELINE.json's strict wording: (primary+secondary)
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"] if not (args.width or args.height) else wl["name"] + " [resized %dx%d]" % (W, H),

@@ -1,0 +1,374 @@
+// rtx_cells.hip.h -- shadow rays through a per-(light, direction cell) candidate table: k_cells_build (once per context), k_shadow_cells (every generation)
+// Part of the one translation unit rtx_device.hip (device code, namespace rtx); not a stand-alone header.
+#ifndef RTX_CELLS_HIP_H_
+#define RTX_CELLS_HIP_H_
+
+namespace rtx {
+
+// ------------------------------------------------------------------------------------------------
+// Every shadow ray's line passes through its light (raytracing.cpp:561-568: the direction is normalize(light - hit
+// point), the origin the hit point moved 1e-4 along the normal), so WHICH plain primitives a shadow ray can touch is a
+// function of its light, of the direction it arrives from and of how far from the light it starts -- nothing else.
+// k_shadow_pass rediscovers that set per wave and frame: a packet per 64 rays, a walk of the cluster hierarchy, two
+// dozen survivors broadcast one at a time.  Here it is tabulated ONCE per context:
+//
+//   cell_off[light * G * G + cell]   CSR offsets, cell = light_cell(direction, G) (octahedral map, Morton order)
+//   cell_ent[...] = { primitive, dneed }   the shadow casters (plain spheres, triangles) some ray of that cell can
+//                                          pass, sorted by dneed: a ray whose origin is nearer than dneed to the light
+//                                          cannot pass this entry nor any later one
+//
+// and a shadow ray of ANY generation walks its own cell's list (one lane = one ray, four entries a step, stopping at
+// the first dneed beyond its own distance), runs the per-ray filter on those, and hands the surviving (ray, primitive)
+// pairs to the pooled exact stages of shadow_plain_pool (S / T / A: 64 pairs at a time, whoever they belong to).  No
+// packet is built, no hierarchy walked, no survivor broadcast; incoherent rays (generations >= 1) cost what coherent
+// ones do.
+//
+// Conservative by the packet argument that k_shadow_pass rests on, evaluated with the CELL as the packet
+// (as k_affine_cells does for affine spheres):
+//   * directions: the unit directions that light_cell maps to one cell are decode(q) / |decode(q)| for q in the cell's
+//     square; decode is linear on each octahedron face, the square lies in one face or is cut by a face diagonal
+//     through two of its corners, and the angle to a fixed axis over a planar convex piece is largest at a vertex: every
+//     direction of the cell is within the largest of the four corner angles of the centre direction (sine taken from
+//     the cross product, 1e-5 added for the rounding of light_cell at the borders).
+//   * origins: apex-at-light packets (make_packet, apex_ok): rho = 1.3e-4 + 3.8e-3 D covers the origin bias, the
+//     filter's angular tolerance and the rounding of the direction for every ray that starts within D of the light.
+//     packet_test is monotone in rho (every operation on the path from rho to the comparison is a rounded monotone
+//     one), so the SMALLEST of 33 levels D_j = dmax j / 32 at which an entry passes is a bound: rays with
+//     D <= D_(j-1) cannot pass it.
+//   * front: a primitive whose bounding sphere lies behind the origin of every ray of the cell that starts within D
+//     of the light, with filt_front's margin (n.(o - c) >= 1.005 R + 1e-3 |o - c|), cannot be hit (t >= 0 only).
+// dneed = max of the two.  Rays the table does not cover -- abnormal ones, origins further than dmax from the light or
+// on top of it, zero directions -- take the transposed scan over every shadow caster, as in k_shadow_pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCellLevels = 32;
+constexpr int kCellCap = 2048;   // entries one build wave sorts in LDS; longer lists are stored unsorted with dneed = -1
+constexpr int kCellPad = 4;      // readable entries behind the last list (the walk loads four at a time)
+
+__device__ __forceinline__ F3 oct_decode(float qx, float qy)
+{
+    const float z = 1.0f - fabsf(qx) - fabsf(qy);
+    if (z >= 0.0f) return f3(qx, qy, z);
+    return f3((1.0f - fabsf(qy)) * (qx >= 0.0f ? 1.0f : -1.0f), (1.0f - fabsf(qx)) * (qy >= 0.0f ? 1.0f : -1.0f), z);
+}
+
+// axis, sin(half-angle) rounded up, cos(half-angle) rounded down of the cone around cell m of the G x G map
+struct CellCone { F3 w; float sT, cLo; };
+
+__device__ __forceinline__ CellCone cell_cone(unsigned m, int G)
+{
+    const float gx = (float)demorton12(m), gy = (float)demorton12(m >> 1), s = 2.0f / (float)G;
+    const F3 vc = oct_decode((gx + 0.5f) * s - 1.0f, (gy + 0.5f) * s - 1.0f);
+    const float in = 1.0f / sqrtf(vc.x * vc.x + vc.y * vc.y + vc.z * vc.z);
+    CellCone K;
+    K.w = f3(vc.x * in, vc.y * in, vc.z * in);
+    float sm = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const F3 v = oct_decode((gx + (float)(u & 1)) * s - 1.0f, (gy + (float)(u >> 1)) * s - 1.0f);
+        const float cx = K.w.y * v.z - K.w.z * v.y, cy = K.w.z * v.x - K.w.x * v.z, cz = K.w.x * v.y - K.w.y * v.x;
+        sm = fmaxf(sm, sqrtf(cx * cx + cy * cy + cz * cz) / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z));
+    }
+    K.sT = sm * 1.0001f + 1e-5f;
+    K.cLo = sqrtf(fmaxf(0.0f, 1.0f - K.sT * K.sT)) - 1e-6f;
+    return K;
+}
+
+// the packet of make_packet(apex_ok) for a cone given directly; rho is set by the caller
+__device__ __forceinline__ Packet cell_packet(const CellCone& K, F3 apex)
+{
+    Packet P;
+    P.co = apex; P.w = K.w; P.rho = 0.0f; P.c0 = K.cLo; P.ok = true;
+    const float cosE = 0.99999316f, sinE = 3.7e-3f;  // the filter's own angular tolerance, as make_packet
+    const float cT = K.cLo * cosE - K.sT * sinE - 4e-6f;
+    const float sT2 = K.sT * cosE + fminf(K.cLo + 2e-6f, 1.0f) * sinE + 4e-6f;
+    P.cosT2 = cT * cT;
+    P.sinT = sT2;
+    return P;
+}
+
+__device__ __forceinline__ float cell_rho(float D) { return 1.3e-4f + 3.8e-3f * D; }  // make_packet's, for one ray at distance D
+
+// One wave per (light, cell).  FILL = false: count the entries (cnt[cell]); FILL = true: collect, sort by dneed, store.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int2* ent)
+{
+    __shared__ int2 buf[FILL ? kCellCap : 1];
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    const int li = cell / (G * G), m = cell % (G * G);
+    const CellCone K = cell_cone((unsigned)m, G);
+    const F3 Lp = f3(S.lights[li].point);
+    Packet P = cell_packet(K, Lp);
+    const float dm = dmax[li];
+    P.rho = cell_rho(dm);
+    const int base = FILL ? off[cell] : 0;
+    int n = 0;
+    for (int cb = 0; cb < S.sncl; cb += 64) {
+        const int c = cb + lane;
+        unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+        while (cm) {
+            const size_t mi = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+            cm &= cm - 1;
+            const float4 mb = S.smem[mi];
+            const int k = S.sidx[mi];
+            const bool keep = k >= 0 && packet_test(P, mb);
+            const unsigned long long bal = __ballot(keep);
+            if (FILL && keep) {
+                // smallest level at which the entry passes (it passes at the last one)
+                int lo = 0, hi = kCellLevels;
+                Packet Pm = P;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    Pm.rho = cell_rho(dm * ((float)mid * (1.0f / (float)kCellLevels)));
+                    if (packet_test(Pm, mb)) hi = mid; else lo = mid + 1;
+                }
+                const float dlev = (lo == 0) ? -1.0f : dm * ((float)(lo - 1) * (1.0f / (float)kCellLevels)) * 0.999999f;
+                // behind every origin within D of the light: n.C <= ub for every direction n of the cell, C = c - light
+                const float Cx = mb.x - Lp.x, Cy = mb.y - Lp.y, Cz = mb.z - Lp.z;
+                const float C2 = Cx * Cx + Cy * Cy + Cz * Cz, Cn = sqrtf(C2);
+                const float wC = K.w.x * Cx + K.w.y * Cy + K.w.z * Cz;
+                const float h = sqrtf(fmaxf(0.0f, C2 - wC * wC)) + 1e-3f * Cn;
+                const float ub = (wC < 0.0f ? wC * K.cLo : wC) + h * K.sT;
+                const float R = sqrtf(-mb.w) * 1.00001f;
+                const float dfront = -ub - 1.005f * R - 1e-3f * (Cn + dm) - 1e-3f;
+                float dneed = fmaxf(dlev, dfront);
+                if (!(R < 1e18f) || dneed != dneed) dneed = -1.0f;  // records that always pass (R = inf): every ray takes them
+                const int pos = n + lanes_below(bal);
+                if (pos < kCellCap) buf[pos] = make_int2(k, __float_as_int(dneed));
+                else ent[(size_t)base + pos] = make_int2(k, __float_as_int(-1.0f));
+            }
+            n += __popcll(bal);
+        }
+    }
+    if (!FILL) {
+        if (lane == 0) cnt[cell] = n;
+        return;
+    }
+    lds_fence();
+    if (n <= kCellCap) {
+        // rank sort: entry i goes to the number of entries that sort before it (ties by position)
+        for (int i = lane; i < n; i += 64) {
+            const int2 e = buf[i];
+            const float key = __int_as_float(e.y);
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                const float kj = __int_as_float(buf[j].y);
+                rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+            }
+            ent[(size_t)base + rank] = e;
+        }
+    } else {
+        for (int i = lane; i < kCellCap; i += 64) ent[(size_t)base + i] = make_int2(buf[i].x, __float_as_int(-1.0f));
+    }
+}
+
+// 64-bit sum of the per-cell counts (the scan kernels work in int: the host checks this against its budget first)
+__global__ __launch_bounds__(kBlock) void k_cells_sum(const int* cnt, int ncell, unsigned long long* sum)
+{
+    unsigned long long v = 0ull;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ncell; i += gridDim.x * kBlock) v += (unsigned long long)(unsigned)cnt[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+}
+
+struct CellsLds {
+    unsigned listS[kSpList];             // ray << 26 | sphere
+    unsigned listT[kSpList];             // ray << 26 | primitive index of a triangle
+    unsigned listA[kSpList];             // the same, for the area stage
+    float listAt[kSpList];               // ... and the t of its plane intersection
+    int hit[64];                         // 1: some primitive blocks ray r
+};
+
+struct CellTab { const int* off; const int2* ent; const float* dmax; int G; };
+
+// PHASE 0 of the shadow pass by table (plain spheres and triangles); affine spheres follow in k_shadow_affine<., false>.
+template <bool EX>
+__global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
+{
+    __shared__ CellsLds lds[kBlock / 64];
+    const int n = *cnt_in;
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    CellsLds& W = lds[threadIdx.x >> 6];
+    constexpr unsigned kPrimMask = (1u << kPoolPrimBits) - 1u;
+    const int lane = threadIdx.x & 63;
+    const int i = base + threadIdx.x;
+    const int ii = (i < n) ? i : 0;
+    const float4 qa = Qi.a[ii], qb = Qi.b[ii];
+    const int id = __float_as_int(qb.z);
+    const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
+    const F3 o = f3(qa.x, qa.y, qa.z);
+    const F3 ld = f3(qa.w, qb.x, qb.y);
+    const F3 nld = normalized(ld);
+    const bool abn = ray_abnormal(o, ld, nld, S.guard);
+    const int li = live ? id / lit_cap : 0;
+    const F3 Lp = f3(S.lights[li].point);
+    const float ax = o.x - Lp.x, ay = o.y - Lp.y, az = o.z - Lp.z;
+    const float D = fsqrt(ax * ax + ay * ay + az * az);  // as make_packet measures it
+    const bool zero_dir = ld.x == 0.0f && ld.y == 0.0f && ld.z == 0.0f;
+    const bool covered = live && !abn && !zero_dir && D <= T.dmax[li] && D >= 1e-2f;
+    if (live) ex_add(ex, EX_RAYS);
+    int pos = 0, end = 0;
+    if (covered) {
+        const int key = li * T.G * T.G + light_cell(nld, T.G);
+        pos = T.off[key];
+        end = T.off[key + 1];
+    }
+    W.hit[lane] = 0;
+    lds_fence();
+    const F3 fd = f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale);
+    int nS = 0, nT = 0, nA = 0;
+
+    // S / T / A: the pooled exact stages of shadow_plain_pool (rtx_shadow.hip.h), same tests on the same records
+    auto run_S = [&](const int cnt) {
+        const int b0 = nS - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listS[b0 + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rn = f3(__shfl(nld.x, rr), __shfl(nld.y, rr), __shfl(nld.z, rr));
+        const float4 hh = S.sph_hot[k];
+        if (has) ex_add(ex, EX_SPH);
+        float t;
+        const bool hit = sphere_test(ro, rn, hh.x, hh.y, hh.z, hh.w, t);
+        if (has && hit) W.hit[rr] = 1;
+        nS = b0;
+        lds_fence();
+    };
+    auto run_A = [&](const int cnt) {
+        const int b0 = nA - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listA[b0 + (has ? lane : 0)];
+        const float t = W.listAt[b0 + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rl = f3(__shfl(ld.x, rr), __shfl(ld.y, rr), __shfl(ld.z, rr));
+        const float4* p = S.tri_hot + (size_t)(k - S.ns) * 5;
+        const float4 q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+        if (has) ex_add(ex, EX_TRI_FULL);
+        const bool hit = triangle_stage2(ro, rl, t, q1, q2, q3, q4);
+        if (has && hit) W.hit[rr] = 1;
+        nA = b0;
+        lds_fence();
+    };
+    auto run_T = [&](const int cnt) {
+        const int b0 = nT - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listT[b0 + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rl = f3(__shfl(ld.x, rr), __shfl(ld.y, rr), __shfl(ld.z, rr));
+        nT = b0;
+        if (S.mt) {  // wave-uniform: RTX_F_TRI_MOLLER_TRUMBORE, one stage
+            const TriRec R = load_tri(S.tri_hot, k - S.ns);
+            float t, vd;
+            if (has) ex_add(ex, EX_TRI_FULL);
+            const bool hit = triangle_test_mt(ro, rl, R, t, vd) && !(t >= __builtin_inff());
+            if (has && hit) W.hit[rr] = 1;
+            lds_fence();
+            return;
+        }
+        const float4* p = S.tri_hot + (size_t)(k - S.ns) * 5;
+        const float4 q0 = p[0], q1 = p[1];
+        const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
+        float t = 0.0f;
+        int exitp = 0;
+        int need = triangle_stage1(ro, rl, q0, q1, e0, e1, t, EX ? &exitp : nullptr);
+        if (!has) need = 0;
+        if (EX && has && !need) ex_tri(ex, exitp);
+        const unsigned long long bal = __ballot(need != 0);
+        if (bal) {  // wave-uniform
+            if (need) {
+                const int p1 = nA + lanes_below(bal);
+                W.listA[p1] = e;
+                W.listAt[p1] = t;
+            }
+            nA += __popcll(bal);
+        }
+        lds_fence();
+        if (nA >= 64) run_A(64);
+    };
+
+    // the walk: four entries of this lane's own list a step
+    while (__any(pos < end)) {
+        const bool act = pos < end;
+        const int p0 = act ? pos : 0;
+        const int2 e0 = T.ent[p0], e1 = T.ent[p0 + 1], e2 = T.ent[p0 + 2], e3 = T.ent[p0 + 3];
+        const bool t0 = act && D >= __int_as_float(e0.y);
+        const bool t1 = t0 && pos + 1 < end && D >= __int_as_float(e1.y);
+        const bool t2 = t1 && pos + 2 < end && D >= __int_as_float(e2.y);
+        const bool t3 = t2 && pos + 3 < end && D >= __int_as_float(e3.y);
+        const float4 b0 = S.bounds[t0 ? e0.x : 0], b1 = S.bounds[t1 ? e1.x : 0], b2 = S.bounds[t2 ? e2.x : 0], b3 = S.bounds[t3 ? e3.x : 0];
+        if (EX) ex_add(ex, EX_FILT, (unsigned)t0 + (unsigned)t1 + (unsigned)t2 + (unsigned)t3);
+        const bool pass[4] = { t0 && filt_front(o, fd, b0), t1 && filt_front(o, fd, b1), t2 && filt_front(o, fd, b2), t3 && filt_front(o, fd, b3) };
+        const int kk[4] = { e0.x, e1.x, e2.x, e3.x };
+        pos = t3 ? pos + 4 : end;  // sorted by dneed: the first entry beyond this ray's distance ends its list
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool ps = pass[u] && kk[u] < S.ns, pt = pass[u] && kk[u] >= S.ns;
+            const unsigned long long balS = __ballot(ps), balT = __ballot(pt);
+            if ((balS | balT) == 0ull) continue;  // wave-uniform
+            const unsigned entv = ((unsigned)lane << kPoolPrimBits) | (unsigned)kk[u];
+            if (ps) W.listS[nS + lanes_below(balS)] = entv;
+            if (pt) W.listT[nT + lanes_below(balT)] = entv;
+            nS += __popcll(balS);
+            nT += __popcll(balT);
+            lds_fence();
+            if (nS >= 64) run_S(64);
+            if (nT >= 64) run_T(64);
+        }
+        if (W.hit[lane]) pos = end;
+    }
+    if (nT > 0) run_T(nT);
+    if (nS > 0) run_S(nS);
+    if (nA > 0) run_A(nA);
+    bool done = W.hit[lane] != 0;
+
+    // Rays the table does not cover are traced one at a time, TRANSPOSED: the ray is broadcast and the 64 lanes take 64
+    // cluster spheres of the shadow hierarchy a round (the per-ray cone test of k_closest_lanes, front half-space only:
+    // the set holds plain primitives), then the 64 members of every passing cluster: filter and exact test.  An abnormal
+    // ray bypasses both bounds and takes the exact test of every member.
+    unsigned long long fallback = __ballot(live && !covered);
+    while (fallback) {
+        const int r = __ffsll((long long)fallback) - 1;
+        fallback &= fallback - 1;
+        auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+        const F3 ro = f3(bc(o.x), bc(o.y), bc(o.z)), rl = f3(bc(ld.x), bc(ld.y), bc(ld.z)), rn = f3(bc(nld.x), bc(nld.y), bc(nld.z));
+        const F3 rfd = f3(rn.x * kDirScale, rn.y * kDirScale, rn.z * kDirScale);
+        const bool rabn = __builtin_amdgcn_readlane((int)abn, r) != 0;
+        bool blocked = false;
+        for (int cb = 0; cb < S.sncl && !blocked; cb += 64) {
+            const int c = cb + lane;
+            bool cpass = false;
+            if (c < S.sncl) {
+                const float4 cs = S.scl[c];  // { c, -R^2 }
+                if (!rabn) ex_add(ex, EX_CONE);
+                cpass = rabn || !(cone_slack_front(ro, rn, make_float4(cs.x, cs.y, cs.z, fsqrt(-cs.w) * 1.00001f)) < 0.0f);
+            }
+            unsigned long long cm = __ballot(cpass);
+            while (cm && !blocked) {
+                const size_t mi = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
+                cm &= cm - 1;
+                const int k = S.sidx[mi];
+                bool hit = false;
+                if (k >= 0) {
+                    if (!rabn) ex_add(ex, EX_FILT);
+                    if (rabn || filt_front(ro, rfd, S.smem[mi])) hit = exact_any(S, k, ro, rl, rn, ex);
+                }
+                blocked = __any(hit);
+            }
+        }
+        if (lane == r && blocked) done = true;
+    }
+    if (live && done) {
+        lit[id] = 0;
+        // the ray leaves the queue: the affine kernel behind this one neither reads its lit byte nor traces it
+        if (S.naff > 0) reinterpret_cast<int*>(Qi.b + i)[2] = -2;
+    }
+    ex_flush(ex, S.exec + 2 * EX_KINDS);
+}
+
+}  // namespace rtx
+#endif

@@ -61,6 +61,7 @@ static thread_local std::string g_last_hip_error;
 #include "rtx_kernels_common.hip.h"
 #include "rtx_closest.hip.h"
 #include "rtx_shadow.hip.h"
+#include "rtx_cells.hip.h"
 #include "rtx_shade.hip.h"
 
 
@@ -134,6 +135,8 @@ struct rtx_context {
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
     hipStream_t last_stream = nullptr;
+    CellTab cells{};                        // (light, direction cell) -> shadow casters (rtx_cells.hip.h); off == nullptr: no table,
+                                            // the packet kernels (k_shadow_pass) trace the plain primitives
     int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
                                             // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
@@ -347,6 +350,109 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.box_lo = {lo[0], lo[1], lo[2]};
             c->S.box_inv = {inv[0], inv[1], inv[2]};
         }
+        // The (light, direction cell) tables cover origins up to the far corner of the scene box (rays from further away,
+        // possible only through the reference's odd hit points on affine spheres, are traced against every sphere).
+        std::vector<float> dt(c->S.nl);
+        for (int l = 0; l < c->S.nl; l++) {
+            double far2 = 0;
+            const float lp[3] = {P.lights[l].point.x, P.lights[l].point.y, P.lights[l].point.z};
+            const float lo[3] = {c->S.box_lo.x, c->S.box_lo.y, c->S.box_lo.z};
+            const float inv[3] = {c->S.box_inv.x, c->S.box_inv.y, c->S.box_inv.z};
+            for (int a = 0; a < 3; a++) {
+                const double hi = (double)lo[a] + 16.0 / (double)inv[a];
+                const double d = std::max(std::fabs((double)lp[a] - lo[a]), std::fabs((double)lp[a] - hi));
+                far2 += d * d;
+            }
+            const double v = std::sqrt(far2) * 1.01 + 1.0;
+            dt[l] = std::isfinite(v) ? (float)v : 0.0f;
+        }
+        float* d_dt = nullptr;
+        if ((rc = c->upload(&d_dt, dt))) return rc;
+        // (light, direction cell) -> plain shadow casters, CSR lists sorted by the distance from the light a ray must
+        // start beyond to pass the entry (rtx_cells.hip.h): count, scan, fill.  Not in arena mode (its size is unknown
+        // before the count) and not for the exact-only / counting frames, which trace no culled shadow rays.
+        c->cells = CellTab{};
+        bool want_cells = !c->arena && c->S.nl > 0 && c->S.sncl > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
+#ifdef RTX_AB_KNOBS
+        if (const char* e = std::getenv("RTX_CELLS")) want_cells = want_cells && std::atoi(e) != 0;
+#endif
+        if (want_cells) {
+            // The table's range: the far corner of the box of the shadow casters themselves, twice over -- not of every bounded
+            // primitive: an affine sphere's world-space ellipsoid can be thousands of units long, rho = 3.8e-3 D then lets every
+            // primitive pass every cell, and hit points that far out are a handful of pixels.  Rays from beyond it take the
+            // transposed scan (k_shadow_cells).
+            std::vector<float> dc(c->S.nl);
+            {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (const BoundSphere& b : P.sbounds) {
+                    if (!std::isfinite(b.neg_r2) || !std::isfinite(b.cx) || !std::isfinite(b.cy) || !std::isfinite(b.cz)) continue;
+                    const double r = std::sqrt(-(double)b.neg_r2);
+                    const double cc[3] = {b.cx, b.cy, b.cz};
+                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cc[a] - r); hi[a] = std::max(hi[a], cc[a] + r); }
+                }
+                for (int l = 0; l < c->S.nl; l++) {
+                    const double lp[3] = {P.lights[l].point.x, P.lights[l].point.y, P.lights[l].point.z};
+                    double far2 = 0;
+                    for (int a = 0; a < 3; a++) {
+                        const double d = (hi[a] >= lo[a]) ? std::max(std::fabs(lp[a] - lo[a]), std::fabs(lp[a] - hi[a])) : 0.0;
+                        far2 += d * d;
+                    }
+                    const double v = 2.0 * std::sqrt(far2) + 1.0;
+                    dc[l] = std::isfinite(v) ? std::min((float)v, dt[l]) : 0.0f;
+                }
+            }
+            float* d_dc = nullptr;
+            if ((rc = c->upload(&d_dc, dc))) return rc;
+            int G = 512;
+#ifdef RTX_AB_KNOBS
+            if (const char* e = std::getenv("RTX_CELL_G")) G = std::max(8, std::min(4096, std::atoi(e)));
+#endif
+            while ((size_t)c->S.nl * G * G > ((size_t)1 << 24) && G > 8) G /= 2;
+            // entries the table may hold: 2^31 by its int offsets, a quarter of the workspace budget by size (8 B each)
+            const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
+            const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 4 / sizeof(int2));
+            int* cnt = nullptr;
+            unsigned long long* d_sum = nullptr;
+            {
+                const size_t ncell0 = (size_t)c->S.nl * G * G;
+                HIPCHK(hipMalloc((void**)&cnt, sizeof(int) * (ncell0 + 2 * ((ncell0 + 1023) / 1024) + 2) + sizeof(unsigned long long)));
+            }
+            auto build = [&]() -> int {
+                for (; G >= 8; G /= 2) {
+                    const int ncell = c->S.nl * G * G;
+                    const int nb = (ncell + 1023) / 1024;
+                    int* bsum = cnt + ncell;
+                    int* braw = bsum + nb;
+                    d_sum = reinterpret_cast<unsigned long long*>(cnt + (((size_t)ncell + 2 * (size_t)nb + 1) & ~(size_t)1));
+                    HIPCHK(hipMemset(d_sum, 0, sizeof(unsigned long long)));
+                    hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)ncell), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr);
+                    hipLaunchKernelGGL(k_cells_sum, dim3(1024), dim3(kBlock), 0, 0, cnt, ncell, d_sum);
+                    HIPCHK(hipGetLastError());
+                    unsigned long long sum = 0;
+                    HIPCHK(hipMemcpy(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost));
+                    if (sum > max_entries) continue;  // a coarser map: a quarter of the cells
+                    const int total = (int)sum;
+                    int* off = nullptr; int2* ent = nullptr;
+                    int r = c->dalloc(&ent, (size_t)total + kCellPad);
+                    if (r == RTX_E_OOM) { (void)hipGetLastError(); continue; }  // no room for this map: a coarser one
+                    if (r) return r;
+                    if ((r = c->dalloc(&off, (size_t)ncell + 1))) return r;
+                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, 0, cnt, off, ncell, bsum, braw, 1);
+                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, bsum, nb, off + ncell);
+                    hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, 0, off, ncell, bsum, braw, 1, (float4*)nullptr);
+                    HIPCHK(hipMemset(ent + total, 0xff, sizeof(int2) * kCellPad));  // primitive -1 / dneed NaN: never taken
+                    hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)ncell), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, ent);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipDeviceSynchronize());
+                    c->cells.off = off; c->cells.ent = ent; c->cells.dmax = d_dc; c->cells.G = G;
+                    return RTX_OK;
+                }
+                return RTX_OK;  // no map is coarse enough: no table, the packet kernels trace the plain primitives
+            };
+            rc = build();
+            (void)hipFree(cnt);
+            if (rc) return rc;
+        }
         c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
         if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0) {
             // (light, direction cell) -> affine spheres table for the shadow passes (k_affine_cells)
@@ -355,24 +461,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             const size_t tab_limit = c->arena ? c->arena_cap / 8 : ((size_t)256 << 20);  // arena mode: the table may take an eighth of the block
             while ((size_t)c->S.nl * G * G * words * 8 > tab_limit && G > 16) G /= 2;
             if ((size_t)c->S.nl * G * G * words * 8 <= tab_limit) {
-                // the table covers origins up to the far corner of the scene box (rays from further away, possible
-                // only through the reference's odd hit points on affine spheres, make their wave test every sphere)
-                std::vector<float> dt(c->S.nl);
-                for (int l = 0; l < c->S.nl; l++) {
-                    double far2 = 0;
-                    const float lp[3] = {P.lights[l].point.x, P.lights[l].point.y, P.lights[l].point.z};
-                    const float lo[3] = {c->S.box_lo.x, c->S.box_lo.y, c->S.box_lo.z};
-                    const float inv[3] = {c->S.box_inv.x, c->S.box_inv.y, c->S.box_inv.z};
-                    for (int a = 0; a < 3; a++) {
-                        const double hi = (double)lo[a] + 16.0 / (double)inv[a];
-                        const double d = std::max(std::fabs((double)lp[a] - lo[a]), std::fabs((double)lp[a] - hi));
-                        far2 += d * d;
-                    }
-                    const double v = std::sqrt(far2) * 1.01 + 1.0;
-                    dt[l] = std::isfinite(v) ? (float)v : 0.0f;
-                }
-                float* d_dt = nullptr; unsigned long long* tab = nullptr;
-                if ((rc = c->upload(&d_dt, dt))) return rc;
+                unsigned long long* tab = nullptr;
                 if ((rc = c->dalloc(&tab, (size_t)c->S.nl * G * G * words))) return rc;
                 const int ncell = c->S.nl * G * G;
                 hipLaunchKernelGGL(k_affine_cells, dim3((unsigned)((ncell + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, 0, c->S, G, d_dt, tab, words);
@@ -764,7 +853,17 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 // later generations take the pooled stages (rtx_shadow.hip.h, shadow_plain_pool)
                 const bool pool = k >= c->pool_from;
 #define RTX_SHADOW_ARGS dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8
-                if (fused) {
+                if (c->cells.off) {
+                    // the plain primitives by table (rtx_cells.hip.h), one workgroup per 256 queue slots at every size; the
+                    // affine spheres behind it for the rays still lit
+                    const dim3 gc(grid_for(live_cap * (size_t)c->S.nl + c->qpad));
+                    if (exec) hipLaunchKernelGGL(k_shadow_cells<true>, gc, dim3(kBlock), 0, ss, c->S, c->cells, sl.q, sc + 0, Lk.lit, Lk.cap);
+                    else hipLaunchKernelGGL(k_shadow_cells<false>, gc, dim3(kBlock), 0, ss, c->S, c->cells, sl.q, sc + 0, Lk.lit, Lk.cap);
+                    if (c->S.naff > 0) {
+                        if (exec) hipLaunchKernelGGL((k_shadow_affine<true, false, false>), RTX_SHADOW_ARGS);
+                        else hipLaunchKernelGGL((k_shadow_affine<false, false, false>), RTX_SHADOW_ARGS);
+                    }
+                } else if (fused) {
                     if (exec) { if (pool) hipLaunchKernelGGL((k_shadow_affine<true, true, true>), RTX_SHADOW_ARGS); else hipLaunchKernelGGL((k_shadow_affine<true, true, false>), RTX_SHADOW_ARGS); }
                     else { if (pool) hipLaunchKernelGGL((k_shadow_affine<false, true, true>), RTX_SHADOW_ARGS); else hipLaunchKernelGGL((k_shadow_affine<false, true, false>), RTX_SHADOW_ARGS); }
                 } else {
@@ -895,7 +994,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G"})  // the A/B aids context creation reads
         if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }

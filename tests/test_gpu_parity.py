@@ -85,6 +85,49 @@ def test_culling_is_exact_on_4k_frame(rt, gpu, c4_scene):
     assert sa.chunks == 1 and sa.queue_overflow == 0 and sb.queue_overflow == 0 and sb.chunks >= 1
 
 
+@pytest.fixture(scope="module")
+def c4_headline_scene(rt, tmp_path_factory):
+    """The UNMODIFIED benchmark scene -- what bench.py renders (scenegen.write_c4 with its defaults)."""
+    p = tmp_path_factory.mktemp("c4h") / "c4.txt"
+    rt.scenegen.write_c4(str(p))
+    return rt.load_scene(str(p))
+
+
+def test_c4_headline_scene_matches_the_reference_fixture(rt, gpu, c4_headline_scene):
+    """The real reference's output on the unmodified C4 scene at depth 5, 48x27 (tests/golden/c4_48x27_d4.*, made by
+    make_golden.py from oracle/_ref/rt_ref): float image, PPM and ray counters."""
+    import json
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    run = [r for r in json.load(open(os.path.join(golden, "index.json")))["runs"] if r["scene"] == "scenegen:c4"][0]
+    W, H, D = run["width"], run["height"], run["max_depth"]
+    raw_ref = np.fromfile(os.path.join(golden, run["raw"]), dtype=np.float32).reshape(H, W, 3)
+    g, st = rt.render_f32(c4_headline_scene, rt.Params.make(W, H, D))
+    same = raw_equal_mask(g, raw_ref)
+    assert same.mean() >= 0.999, int((~same).sum())
+    rgb, _ = rt.render_rgb8(c4_headline_scene, rt.Params.make(W, H, D))
+    data = open(os.path.join(golden, run["ppm"]), "rb").read()
+    ppm = np.frombuffer(data[data.index(b"255\n") + 4:], dtype=np.uint8).reshape(H, W, 3)
+    assert_rgb8_parity(rgb, ppm, "c4 48x27")
+
+
+def test_c4_headline_scene_crop_matches_oracle_at_4k(rt, oracle, gpu, c4_headline_scene):
+    """The benchmark frame's own geometry (3840x2160, depth 5): rows 1200..1203 against the oracle, and the whole
+    frame culled against exact-only, byte for byte."""
+    W, H = 3840, 2160
+    row0, row1 = 1200, 1204
+    raw_cpu, cnt = oracle.render_f32(c4_headline_scene, W, H, 4, row0, row1)
+    p = rt.Params.make(W, H, 4, nranks=540, rank=300, band_rows=4)   # the band that is exactly those rows
+    raw_gpu, st = rt.render_f32(c4_headline_scene, p)
+    assert raw_gpu.shape == raw_cpu.shape
+    same = raw_equal_mask(raw_gpu, raw_cpu)
+    print("c4 headline crop: %d of %d pixels bit-identical" % (int(same.sum()), same.size))
+    assert same.mean() >= 0.999
+    ra, sa = rt.render_rgb8(c4_headline_scene, rt.Params.make(W, H, 4))
+    rb, sb = rt.render_rgb8(c4_headline_scene, rt.Params.make(W, H, 4, flags=rt.host.F_EXACT_ONLY))
+    assert (sa.rays_primary, sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_primary, sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert np.array_equal(ra, rb), "%d bytes differ" % int((ra != rb).sum())
+
+
 def test_culling_is_exact_across_segments(rt, gpu, tmp_path):
     """45,000 primitives = two 32,768-primitive segments of the closest-hit hierarchy; 800x450 > 2^18 rays
     so generation 0 runs the packet kernel."""
