@@ -170,56 +170,119 @@ __global__ __launch_bounds__(kBlock) void k_cells_sum(const int* cnt, int ncell,
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Affine spheres (raytracing.cpp:571-576: only the DIRECTION of a shadow ray is mapped into object space, the origin
+// stays where it is): which of them a shadow ray can pass depends on where along its line the ray starts, not only on
+// the line.  The table holds, per (light, cell), the affine spheres that pass the strip test of k_affine_cells for the
+// cell's rays (affine_strip_pass with the cell as the packet) and, for each, a 32-bit mask of the SLABS of origin
+// distance D in which they still do: slab s = [s, s + 1] dmax / 32, widened by 1e-4 dmax either side; the strip
+// packet of a slab has D in that range and origins within D_hi chord of the axis.  A ray looks at the entries of its
+// cell whose mask has the bit of its own slab, runs filt_affine on those and hands the survivors to a pooled exact stage.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAffSlabs = 32;
+
+__device__ __forceinline__ StripPacket cell_strip(const CellCone& K, F3 light, float Da, float Db)
+{
+    StripPacket P;
+    P.w = K.w;
+    P.Lr = light;
+    P.chord = K.sT / K.cLo * 1.0001f + 1e-6f;  // |ld - w| = 2 sin(theta / 2) <= tan(theta)
+    P.Dmin = Da * K.cLo - 1e-3f;               // (L - o).w >= |L - o| cos(theta), less the origin bias
+    P.Dmax = Db * 1.001f + 1e-3f;
+    P.Dfar = Db * 1.001f + 1e-3f;
+    P.rperp = Db * P.chord * 1.01f + 3e-4f;
+    return P;
+}
+
+// One wave per (light, cell); the lists are per (light, cell, SLAB): cnt / off are indexed by cell * kAffSlabs + slab and an
+// entry is the index of the sphere's record in aff_shadow.  Both passes run the slab tests (the count must match the fill).
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int* ent)
+{
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    const int li = cell / (G * G), m = cell % (G * G);
+    const CellCone K = cell_cone((unsigned)m, G);
+    const F3 Lp = f3(S.lights[li].point);
+    const float dm = dmax[li];
+    const StripPacket K0 = cell_strip(K, Lp, 0.0f, dm);
+    const float slab = dm * (1.0f / (float)kAffSlabs), eps = 1e-4f * dm;
+    int mine = 0;  // lane s: entries of slab s so far
+    const int base = (FILL && lane < kAffSlabs) ? off[(size_t)cell * kAffSlabs + lane] : 0;
+    for (int a0 = 0; a0 < S.naff; a0 += 64) {
+        const int ai = min(a0 + lane, S.naff - 1);
+        const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+        const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+        unsigned mask = 0u;
+        if (a0 + lane < S.naff && affine_strip_pass(K0, m0, m1, m2, m3)) {
+            for (int sl = 0; sl < kAffSlabs; sl++) {
+                const StripPacket Ks = cell_strip(K, Lp, fmaxf(0.0f, (float)sl * slab - eps), (float)(sl + 1) * slab + eps);
+                if (affine_strip_pass(Ks, m0, m1, m2, m3)) mask |= 1u << sl;
+            }
+        }
+        if (__ballot(mask != 0u) == 0ull) continue;  // wave-uniform
+        for (int sl = 0; sl < kAffSlabs; sl++) {
+            const bool in = (mask >> sl) & 1u;
+            const unsigned long long bal = __ballot(in);
+            if (bal == 0ull) continue;
+            const int before = __builtin_amdgcn_readlane(mine, sl), b0 = __builtin_amdgcn_readlane(base, sl);
+            if (FILL && in) ent[(size_t)b0 + before + lanes_below(bal)] = ai;
+            if (lane == sl) mine += __popcll(bal);
+        }
+    }
+    if (!FILL && lane < kAffSlabs) cnt[(size_t)cell * kAffSlabs + lane] = mine;
+}
+
 struct CellsLds {
     unsigned listS[kSpList];             // ray << 26 | sphere
     unsigned listT[kSpList];             // ray << 26 | primitive index of a triangle
     unsigned listA[kSpList];             // the same, for the area stage
     float listAt[kSpList];               // ... and the t of its plane intersection
+    unsigned listX[kSpList];             // ray << 26 | affine sphere (primitive index)
     int hit[64];                         // 1: some primitive blocks ray r
 };
 
-struct CellTab { const int* off; const int2* ent; const float* dmax; int G; };
+// (light, cell) tables: plain shadow casters { primitive, dneed } and affine spheres { record, slab mask }.
+// aoff == nullptr: no affine table (the caller runs k_shadow_affine behind the walk when the scene has affine spheres).
+struct CellTab {
+    const int* off; const int2* ent; const float* dmax; int G;
+    const int* aoff; const int* aent; int aG;   // affine lists per (light, cell, slab)
+};
 
-// PHASE 0 of the shadow pass by table (plain spheres and triangles); affine spheres follow in k_shadow_affine<., false>.
+// One lane = one shadow ray (o, ld) towards light li.  Returns true for the lanes whose ray is blocked by a plain
+// primitive or -- with an affine table -- by an affine sphere.
 template <bool EX>
-__global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
+__device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const CellTab& T, CellsLds& W, const bool live, const F3 o, const F3 ld,
+                                                   const int li, Exec* ex)
 {
-    __shared__ CellsLds lds[kBlock / 64];
-    const int n = *cnt_in;
-    const int base = blockIdx.x * kBlock;
-    if (base >= n) return;  // block-uniform
-    Exec exs;
-    Exec* ex = EX ? &exs : nullptr;
-    ex_zero(ex);
-    CellsLds& W = lds[threadIdx.x >> 6];
     constexpr unsigned kPrimMask = (1u << kPoolPrimBits) - 1u;
     const int lane = threadIdx.x & 63;
-    const int i = base + threadIdx.x;
-    const int ii = (i < n) ? i : 0;
-    const float4 qa = Qi.a[ii], qb = Qi.b[ii];
-    const int id = __float_as_int(qb.z);
-    const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
-    const F3 o = f3(qa.x, qa.y, qa.z);
-    const F3 ld = f3(qa.w, qb.x, qb.y);
     const F3 nld = normalized(ld);
     const bool abn = ray_abnormal(o, ld, nld, S.guard);
-    const int li = live ? id / lit_cap : 0;
     const F3 Lp = f3(S.lights[li].point);
     const float ax = o.x - Lp.x, ay = o.y - Lp.y, az = o.z - Lp.z;
     const float D = fsqrt(ax * ax + ay * ay + az * az);  // as make_packet measures it
     const bool zero_dir = ld.x == 0.0f && ld.y == 0.0f && ld.z == 0.0f;
-    const bool covered = live && !abn && !zero_dir && D <= T.dmax[li] && D >= 1e-2f;
+    const float dm = T.dmax[li];
+    const bool covered = live && !abn && !zero_dir && D <= dm && D >= 1e-2f;
     if (live) ex_add(ex, EX_RAYS);
-    int pos = 0, end = 0;
+    int pos = 0, end = 0, posA = 0, endA = 0;
     if (covered) {
-        const int key = li * T.G * T.G + light_cell(nld, T.G);
+        const int cell = light_cell(nld, T.G);
+        const int key = li * T.G * T.G + cell;
         pos = T.off[key];
         end = T.off[key + 1];
+        if (T.aoff) {
+            const int cellA = (T.aG == T.G) ? cell : light_cell(nld, T.aG);
+            const int slab = min(kAffSlabs - 1, (int)(D * ((float)kAffSlabs / dm)));
+            const size_t keyA = ((size_t)li * T.aG * T.aG + cellA) * kAffSlabs + slab;
+            posA = T.aoff[keyA];
+            endA = T.aoff[keyA + 1];
+        }
     }
     W.hit[lane] = 0;
     lds_fence();
     const F3 fd = f3(nld.x * kDirScale, nld.y * kDirScale, nld.z * kDirScale);
-    int nS = 0, nT = 0, nA = 0;
+    int nS = 0, nT = 0, nA = 0, nX = 0;
 
     // S / T / A: the pooled exact stages of shadow_plain_pool (rtx_shadow.hip.h), same tests on the same records
     auto run_S = [&](const int cnt) {
@@ -235,6 +298,23 @@ __global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, 
         const bool hit = sphere_test(ro, rn, hh.x, hh.y, hh.z, hh.w, t);
         if (has && hit) W.hit[rr] = 1;
         nS = b0;
+        lds_fence();
+    };
+    // X: exact affine-sphere tests (raytracing.cpp:571-582): direction through the inverse matrix, origin as it is
+    auto run_X = [&](const int cnt) {
+        const int b0 = nX - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listX[b0 + (has ? lane : 0)];
+        const int k = (int)(e & kPrimMask), rr = (int)(e >> kPoolPrimBits);
+        const F3 ro = f3(__shfl(o.x, rr), __shfl(o.y, rr), __shfl(o.z, rr));
+        const F3 rl = f3(__shfl(ld.x, rr), __shfl(ld.y, rr), __shfl(ld.z, rr));
+        const float4 hh = S.sph_hot[k];
+        const F3 td = normalized(inv_apply(rl, S.sph_im[k]));
+        if (has) ex_add(ex, EX_SPHX);
+        float t;
+        const bool hit = sphere_test(ro, td, hh.x, hh.y, hh.z, hh.w, t);
+        if (has && hit) W.hit[rr] = 1;
+        nX = b0;
         lds_fence();
     };
     auto run_A = [&](const int cnt) {
@@ -324,12 +404,34 @@ __global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, 
     if (nT > 0) run_T(nT);
     if (nS > 0) run_S(nS);
     if (nA > 0) run_A(nA);
+
+    // affine spheres, for the rays still lit: the list of the ray's own (light, cell, slab), mostly empty
+    if (T.aoff) {  // kernel-uniform
+        if (W.hit[lane]) posA = endA;
+        while (__any(posA < endA)) {
+            const bool act = posA < endA;
+            const float4* r0 = S.aff_shadow + (size_t)T.aent[act ? posA : 0] * 4;
+            const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2], a3 = r0[3];
+            if (EX && act) ex_add(ex, EX_AFILT);
+            const bool pass = act && !(filt_affine(o, ld, a0, a1, a2, a3) < 0.0f);
+            posA += 1;
+            const unsigned long long bal = __ballot(pass);
+            if (bal != 0ull) {  // wave-uniform
+                if (pass) W.listX[nX + lanes_below(bal)] = ((unsigned)lane << kPoolPrimBits) | (unsigned)__float_as_int(a3.y);
+                nX += __popcll(bal);
+                lds_fence();
+                if (nX >= 64) run_X(64);
+                if (W.hit[lane]) posA = endA;
+            }
+        }
+        if (nX > 0) run_X(nX);
+    }
     bool done = W.hit[lane] != 0;
 
-    // Rays the table does not cover are traced one at a time, TRANSPOSED: the ray is broadcast and the 64 lanes take 64
+    // Rays the tables do not cover are traced one at a time, TRANSPOSED: the ray is broadcast and the 64 lanes take 64
     // cluster spheres of the shadow hierarchy a round (the per-ray cone test of k_closest_lanes, front half-space only:
-    // the set holds plain primitives), then the 64 members of every passing cluster: filter and exact test.  An abnormal
-    // ray bypasses both bounds and takes the exact test of every member.
+    // the set holds plain primitives), then the 64 members of every passing cluster: filter and exact test; then -- with
+    // an affine table -- 64 affine spheres a round.  An abnormal ray bypasses the bounds and takes every exact test.
     unsigned long long fallback = __ballot(live && !covered);
     while (fallback) {
         const int r = __ffsll((long long)fallback) - 1;
@@ -360,13 +462,68 @@ __global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, 
                 blocked = __any(hit);
             }
         }
+        for (int a0 = 0; T.aoff && a0 < S.naff && !blocked; a0 += 64) {
+            const int ai = a0 + lane;
+            bool hit = false;
+            if (ai < S.naff) {
+                const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
+                const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
+                if (!rabn) ex_add(ex, EX_AFILT);
+                if (rabn || !(filt_affine(ro, rl, m0, m1, m2, m3) < 0.0f)) hit = exact_any(S, __float_as_int(m3.y), ro, rl, rn, ex);
+            }
+            blocked = __any(hit);
+        }
         if (lane == r && blocked) done = true;
     }
+    return done;
+}
+
+// The shadow pass by table over a SORTED queue (k_shadow_bin / k_scan_* / k_shadow_scatter in front of it).
+template <bool EX>
+__global__ __launch_bounds__(kBlock) void k_shadow_cells(SceneDev S, CellTab T, ShadowQ Qi, const int* cnt_in, unsigned char* lit, int lit_cap)
+{
+    __shared__ CellsLds lds[kBlock / 64];
+    const int n = *cnt_in;
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    const int i = base + threadIdx.x;
+    const int ii = (i < n) ? i : 0;
+    const float4 qa = Qi.a[ii], qb = Qi.b[ii];
+    const int id = __float_as_int(qb.z);
+    const bool live = (i < n) && id >= 0;  // id < 0: alignment padding of the bin groups
+    const bool done = shadow_table_trace<EX>(S, T, lds[threadIdx.x >> 6], live, f3(qa.x, qa.y, qa.z), f3(qa.w, qb.x, qb.y), live ? id / lit_cap : 0, ex);
     if (live && done) {
         lit[id] = 0;
-        // the ray leaves the queue: the affine kernel behind this one neither reads its lit byte nor traces it
-        if (S.naff > 0) reinterpret_cast<int*>(Qi.b + i)[2] = -2;
+        // no affine table: the ray leaves the queue, the affine kernel behind this one neither reads its lit byte nor traces it
+        if (S.naff > 0 && !T.aoff) reinterpret_cast<int*>(Qi.b + i)[2] = -2;
     }
+    ex_flush(ex, S.exec + 2 * EX_KINDS);
+}
+
+// The same straight off the hit records, no queue and no sort: thread = hit, blockIdx.y = light; writes every lit flag.
+template <bool EX>
+__global__ __launch_bounds__(kBlock) void k_shadow_direct(SceneDev S, CellTab T, LevelDev L, const int* nnodes)
+{
+    __shared__ CellsLds lds[kBlock / 64];
+    const int n = min(*nnodes, L.cap);
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    const int j = base + threadIdx.x, li = blockIdx.y;
+    const bool live = j < n;
+    const int jj = live ? j : 0;
+    const rtx_light& Lt = S.lights[li];
+    const F3 ip = f3(L.n_px[jj], L.n_py[jj], L.n_pz[jj]);
+    const F3 nn = f3(L.n_nx[jj], L.n_ny[jj], L.n_nz[jj]);
+    const F3 ld = normalized(f3(Lt.point.x - ip.x, Lt.point.y - ip.y, Lt.point.z - ip.z));        // :561-562
+    const F3 o = f3(ip.x + nn.x * kBias, ip.y + nn.y * kBias, ip.z + nn.z * kBias);                // :568
+    const bool done = shadow_table_trace<EX>(S, T, lds[threadIdx.x >> 6], live, o, ld, li, ex);
+    if (live) L.lit[(size_t)li * L.cap + j] = done ? 0 : 1;
     ex_flush(ex, S.exec + 2 * EX_KINDS);
 }
 

@@ -137,6 +137,7 @@ struct rtx_context {
     hipStream_t last_stream = nullptr;
     CellTab cells{};                        // (light, direction cell) -> shadow casters (rtx_cells.hip.h); off == nullptr: no table,
                                             // the packet kernels (k_shadow_pass) trace the plain primitives
+    bool shadow_direct = false;             // the table kernels read the hit records themselves: no shadow queue, no sort (k_shadow_direct)
     int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
                                             // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
@@ -377,19 +378,21 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (const char* e = std::getenv("RTX_CELLS")) want_cells = want_cells && std::atoi(e) != 0;
 #endif
         if (want_cells) {
-            // The table's range: the far corner of the box of the shadow casters themselves, twice over -- not of every bounded
-            // primitive: an affine sphere's world-space ellipsoid can be thousands of units long, rho = 3.8e-3 D then lets every
-            // primitive pass every cell, and hit points that far out are a handful of pixels.  Rays from beyond it take the
-            // transposed scan (k_shadow_cells).
+            // The tables' range: the far corner of the box of the shadow casters themselves (an affine sphere as it sits for a
+            // shadow ray: its centre and radius as given, raytracing.cpp:571-576), twice over -- not of every bounded
+            // primitive: an affine sphere's world-space ellipsoid can be thousands of units long, rho = 3.8e-3 D then lets
+            // every primitive pass every cell, and hit points that far out are a handful of pixels.  Rays from beyond it take
+            // the transposed scan (shadow_table_trace).
             std::vector<float> dc(c->S.nl);
             {
                 double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                for (const BoundSphere& b : P.sbounds) {
-                    if (!std::isfinite(b.neg_r2) || !std::isfinite(b.cx) || !std::isfinite(b.cy) || !std::isfinite(b.cz)) continue;
-                    const double r = std::sqrt(-(double)b.neg_r2);
-                    const double cc[3] = {b.cx, b.cy, b.cz};
+                auto grow = [&](double x, double y, double z, double r) {
+                    if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z) || !std::isfinite(r)) return;
+                    const double cc[3] = {x, y, z};
                     for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cc[a] - r); hi[a] = std::max(hi[a], cc[a] + r); }
-                }
+                };
+                for (const BoundSphere& b : P.sbounds) grow(b.cx, b.cy, b.cz, std::sqrt(-(double)b.neg_r2));
+                for (const AffineShadowRec& a : P.aff_shadow) grow(a.ox, a.oy, a.oz, std::sqrt(-(double)a.neg_r2));
                 for (int l = 0; l < c->S.nl; l++) {
                     const double lp[3] = {P.lights[l].point.x, P.lights[l].point.y, P.lights[l].point.z};
                     double far2 = 0;
@@ -403,59 +406,83 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             }
             float* d_dc = nullptr;
             if ((rc = c->upload(&d_dc, dc))) return rc;
-            int G = 512;
+            int G0 = 512;
 #ifdef RTX_AB_KNOBS
-            if (const char* e = std::getenv("RTX_CELL_G")) G = std::max(8, std::min(4096, std::atoi(e)));
+            if (const char* e = std::getenv("RTX_CELL_G")) G0 = std::max(8, std::min(4096, std::atoi(e)));
 #endif
-            while ((size_t)c->S.nl * G * G > ((size_t)1 << 24) && G > 8) G /= 2;
-            // entries the table may hold: 2^31 by its int offsets, a quarter of the workspace budget by size (8 B each)
+            while ((size_t)c->S.nl * G0 * G0 > ((size_t)1 << 24) && G0 > 8) G0 /= 2;
+            // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
-            const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 4 / sizeof(int2));
+            const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
             int* cnt = nullptr;
-            unsigned long long* d_sum = nullptr;
             {
-                const size_t ncell0 = (size_t)c->S.nl * G * G;
+                const size_t ncell0 = std::max((size_t)c->S.nl * G0 * G0, (size_t)1 << 24);
                 HIPCHK(hipMalloc((void**)&cnt, sizeof(int) * (ncell0 + 2 * ((ncell0 + 1023) / 1024) + 2) + sizeof(unsigned long long)));
             }
-            auto build = [&]() -> int {
-                for (; G >= 8; G /= 2) {
-                    const int ncell = c->S.nl * G * G;
+            // count, 64-bit sum against the budget (a coarser map if it does not fit), scan, fill.  The plain table has one
+            // list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
+            auto build = [&](const bool affine, const int** off_out, const void** ent_out, int* G_out) -> int {
+                const int mult = affine ? kAffSlabs : 1;
+                const size_t esz = affine ? sizeof(int) : sizeof(int2);
+                for (int G = G0; G >= 8; G /= 2) {
+                    if ((size_t)c->S.nl * G * G * mult > ((size_t)1 << 24)) continue;
+                    const int nwave = c->S.nl * G * G;       // one build wave per (light, cell)
+                    const int ncell = nwave * mult;          // lists
                     const int nb = (ncell + 1023) / 1024;
                     int* bsum = cnt + ncell;
                     int* braw = bsum + nb;
-                    d_sum = reinterpret_cast<unsigned long long*>(cnt + (((size_t)ncell + 2 * (size_t)nb + 1) & ~(size_t)1));
+                    unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(cnt + (((size_t)ncell + 2 * (size_t)nb + 1) & ~(size_t)1));
                     HIPCHK(hipMemset(d_sum, 0, sizeof(unsigned long long)));
-                    hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)ncell), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr);
+                    if (affine) hipLaunchKernelGGL(k_aff_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int*)nullptr);
+                    else hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr);
                     hipLaunchKernelGGL(k_cells_sum, dim3(1024), dim3(kBlock), 0, 0, cnt, ncell, d_sum);
                     HIPCHK(hipGetLastError());
                     unsigned long long sum = 0;
                     HIPCHK(hipMemcpy(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost));
                     if (sum > max_entries) continue;  // a coarser map: a quarter of the cells
                     const int total = (int)sum;
-                    int* off = nullptr; int2* ent = nullptr;
-                    int r = c->dalloc(&ent, (size_t)total + kCellPad);
+                    int* off = nullptr; char* ent = nullptr;
+                    int r = c->dalloc(&ent, ((size_t)total + kCellPad) * esz);
                     if (r == RTX_E_OOM) { (void)hipGetLastError(); continue; }  // no room for this map: a coarser one
                     if (r) return r;
                     if ((r = c->dalloc(&off, (size_t)ncell + 1))) return r;
                     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, 0, cnt, off, ncell, bsum, braw, 1);
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, bsum, nb, off + ncell);
                     hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, 0, off, ncell, bsum, braw, 1, (float4*)nullptr);
-                    HIPCHK(hipMemset(ent + total, 0xff, sizeof(int2) * kCellPad));  // primitive -1 / dneed NaN: never taken
-                    hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)ncell), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, ent);
+                    // the walks read a few entries past a list's end: plain { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
+                    HIPCHK(hipMemset(ent + (size_t)total * esz, affine ? 0 : 0xff, esz * kCellPad));
+                    if (affine) hipLaunchKernelGGL(k_aff_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int*>(ent));
+                    else hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int2*>(ent));
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipDeviceSynchronize());
-                    c->cells.off = off; c->cells.ent = ent; c->cells.dmax = d_dc; c->cells.G = G;
+                    *off_out = off; *ent_out = ent; *G_out = G;
                     return RTX_OK;
                 }
-                return RTX_OK;  // no map is coarse enough: no table, the packet kernels trace the plain primitives
+                return RTX_OK;  // no map is coarse enough: no table
             };
-            rc = build();
+            {
+                const void* e = nullptr;
+                rc = build(false, &c->cells.off, &e, &c->cells.G);
+                c->cells.ent = static_cast<const int2*>(e);
+                // (without the plain table the packet kernels trace everything, with their own affine stage)
+                if (!rc && c->cells.off && c->S.naff > 0) {
+                    e = nullptr;
+                    rc = build(true, &c->cells.aoff, &e, &c->cells.aG);
+                    c->cells.aent = static_cast<const int*>(e);
+                }
+            }
             (void)hipFree(cnt);
             if (rc) return rc;
+            c->cells.dmax = d_dc;
+            c->shadow_direct = c->cells.off && (c->S.naff == 0 || c->cells.aoff);
+#ifdef RTX_AB_KNOBS
+            if (const char* e = std::getenv("RTX_SHADOW_DIRECT")) c->shadow_direct = c->shadow_direct && std::atoi(e) != 0;
+#endif
         }
         c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
-        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0) {
-            // (light, direction cell) -> affine spheres table for the shadow passes (k_affine_cells)
+        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0 && !c->cells.aoff) {
+            // (light, direction cell) -> affine spheres bit masks for k_shadow_affine (k_affine_cells): only where the list
+            // form above does not exist
             const int words = (c->S.naff + 63) / 64;
             int G = 256;
             const size_t tab_limit = c->arena ? c->arena_cap / 8 : ((size_t)256 << 20);  // arena mode: the table may take an eighth of the block
@@ -690,6 +717,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         for (int i = 0; i <= nside; i++) {
             if (i == nside && c->main_from >= levels) break;
             rtx_context::ShadowLane& sl = c->side[i == nside ? (int)rtx_context::kSide : i];
+            if (c->shadow_direct) continue;  // the table kernels read the hit records themselves: no queue, no sort buffers
             if ((rc = c->dalloc(&sl.q.a, qcap))) return rc;
             if ((rc = c->dalloc(&sl.q.b, qcap))) return rc;
             if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
@@ -833,15 +861,17 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                     forked[k] = true;
                 }
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
-                HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
-                hipLaunchKernelGGL(k_shadow_bin, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
-                {
-                    const int nb = (c->nbins + 1023) / 1024;
-                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
-                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
+                if (!c->shadow_direct) {
+                    HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
+                    hipLaunchKernelGGL(k_shadow_bin, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
+                    {
+                        const int nb = (c->nbins + 1023) / 1024;
+                        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, ss, sl.hist, sl.offs, c->nbins, sl.bsum, sl.braw, 64);
+                        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ss, sl.bsum, nb, sc + 0);
+                        hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, ss, sl.offs, c->nbins, sl.bsum, sl.braw, 64, sl.q.b);
+                    }
+                    hipLaunchKernelGGL(k_shadow_scatter, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 }
-                hipLaunchKernelGGL(k_shadow_scatter, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.offs, sl.rank, sl.q);
                 unsigned gq = grid_for(live_cap * (size_t)c->S.nl + c->qpad);  // + the alignment padding of the bin groups
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split4)) * kSplit));
                 gq = std::max(gq, (unsigned)(grid_for(std::min<size_t>(live_cap * (size_t)c->S.nl + c->qpad, (size_t)c->split8)) * 2 * kSplit));
@@ -853,13 +883,19 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 // later generations take the pooled stages (rtx_shadow.hip.h, shadow_plain_pool)
                 const bool pool = k >= c->pool_from;
 #define RTX_SHADOW_ARGS dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8
-                if (c->cells.off) {
-                    // the plain primitives by table (rtx_cells.hip.h), one workgroup per 256 queue slots at every size; the
-                    // affine spheres behind it for the rays still lit
+                if (c->shadow_direct) {
+                    // the whole shadow stage of this generation in ONE launch: every (hit, light) pair walks the tables
+                    // (rtx_cells.hip.h) straight off the hit records -- no queue, no sort
+                    const dim3 gd(g, (unsigned)c->S.nl);
+                    if (exec) hipLaunchKernelGGL(k_shadow_direct<true>, gd, dim3(kBlock), 0, ss, c->S, c->cells, Lk, nodes + k);
+                    else hipLaunchKernelGGL(k_shadow_direct<false>, gd, dim3(kBlock), 0, ss, c->S, c->cells, Lk, nodes + k);
+                } else if (c->cells.off) {
+                    // the sorted queue through the tables, one workgroup per 256 queue slots at every size; without an affine
+                    // table the affine spheres behind it for the rays still lit
                     const dim3 gc(grid_for(live_cap * (size_t)c->S.nl + c->qpad));
                     if (exec) hipLaunchKernelGGL(k_shadow_cells<true>, gc, dim3(kBlock), 0, ss, c->S, c->cells, sl.q, sc + 0, Lk.lit, Lk.cap);
                     else hipLaunchKernelGGL(k_shadow_cells<false>, gc, dim3(kBlock), 0, ss, c->S, c->cells, sl.q, sc + 0, Lk.lit, Lk.cap);
-                    if (c->S.naff > 0) {
+                    if (c->S.naff > 0 && !c->cells.aoff) {
                         if (exec) hipLaunchKernelGGL((k_shadow_affine<true, false, false>), RTX_SHADOW_ARGS);
                         else hipLaunchKernelGGL((k_shadow_affine<false, false, false>), RTX_SHADOW_ARGS);
                     }
@@ -994,7 +1030,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT"})  // the A/B aids context creation reads
         if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }
