@@ -214,9 +214,14 @@ __global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float
         const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
         unsigned mask = 0u;
         if (a0 + lane < S.naff && affine_strip_pass(K0, m0, m1, m2, m3)) {
-            for (int sl = 0; sl < kAffSlabs; sl++) {
-                const StripPacket Ks = cell_strip(K, Lp, fmaxf(0.0f, (float)sl * slab - eps), (float)(sl + 1) * slab + eps);
-                if (affine_strip_pass(Ks, m0, m1, m2, m3)) mask |= 1u << sl;
+            // four slabs at a time first (a wider range of D contains its slabs' packets), then the slabs of the groups that pass
+            for (int g = 0; g < kAffSlabs; g += 4) {
+                const StripPacket Kg = cell_strip(K, Lp, fmaxf(0.0f, (float)g * slab - eps), (float)(g + 4) * slab + eps);
+                if (!affine_strip_pass(Kg, m0, m1, m2, m3)) continue;
+                for (int sl = g; sl < g + 4; sl++) {
+                    const StripPacket Ks = cell_strip(K, Lp, fmaxf(0.0f, (float)sl * slab - eps), (float)(sl + 1) * slab + eps);
+                    if (affine_strip_pass(Ks, m0, m1, m2, m3)) mask |= 1u << sl;
+                }
             }
         }
         if (__ballot(mask != 0u) == 0ull) continue;  // wave-uniform

@@ -138,6 +138,8 @@ struct rtx_context {
     CellTab cells{};                        // (light, direction cell) -> shadow casters (rtx_cells.hip.h); off == nullptr: no table,
                                             // the packet kernels (k_shadow_pass) trace the plain primitives
     bool shadow_direct = false;             // the table kernels read the hit records themselves: no shadow queue, no sort (k_shadow_direct)
+    bool use_cells = false;                 // this context's shadow stage goes through the tables (false: the packet kernels, k_shadow_pass)
+    std::vector<void*> table_allocs, packet_allocs;  // what only one of the two forms needs (the other's is freed once the form is chosen)
     int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
                                             // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
@@ -168,6 +170,15 @@ struct rtx_context {
         *p = (T*)q;
         return RTX_OK;
     }
+    void dfree_group(std::vector<void*>& grp)
+    {
+        if (arena) { grp.clear(); return; }
+        for (void* q : grp) {
+            auto it = std::find(allocs.begin(), allocs.end(), q);
+            if (it != allocs.end()) { (void)hipFree(q); allocs.erase(it); }
+        }
+        grp.clear();
+    }
     template <typename T> int upload(T** p, const std::vector<T>& v)
     {
         int rc = dalloc(p, v.size());
@@ -196,6 +207,7 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
 }
 
 static int calibrate_counts(rtx_context* c, int* d_blk);
+static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out);
 
 static int context_create_impl(const rtx_scene* scene, const rtx_params* params, rtx_context* c)
 {
@@ -460,6 +472,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 }
                 return RTX_OK;  // no map is coarse enough: no table
             };
+            const size_t tab_mark = c->allocs.size();
             {
                 const void* e = nullptr;
                 rc = build(false, &c->cells.off, &e, &c->cells.G);
@@ -474,15 +487,17 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             (void)hipFree(cnt);
             if (rc) return rc;
             c->cells.dmax = d_dc;
+            c->table_allocs.assign(c->allocs.begin() + tab_mark, c->allocs.end());
+            c->use_cells = c->cells.off != nullptr;
             c->shadow_direct = c->cells.off && (c->S.naff == 0 || c->cells.aoff);
 #ifdef RTX_AB_KNOBS
             if (const char* e = std::getenv("RTX_SHADOW_DIRECT")) c->shadow_direct = c->shadow_direct && std::atoi(e) != 0;
 #endif
         }
         c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
-        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0 && !c->cells.aoff) {
-            // (light, direction cell) -> affine spheres bit masks for k_shadow_affine (k_affine_cells): only where the list
-            // form above does not exist
+        const size_t bitmask_mark = c->allocs.size();
+        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0) {
+            // (light, direction cell) -> affine spheres bit masks for the packet form's k_shadow_affine (k_affine_cells)
             const int words = (c->S.naff + 63) / 64;
             int G = 256;
             const size_t tab_limit = c->arena ? c->arena_cap / 8 : ((size_t)256 << 20);  // arena mode: the table may take an eighth of the block
@@ -497,6 +512,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 c->S.aff_cells = tab; c->S.aff_dt = d_dt; c->S.aff_words = words; c->S.aff_G = G;
             }
         }
+        c->packet_allocs.assign(c->allocs.begin() + bitmask_mark, c->allocs.end());
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
         if ((rc = c->upload(&iy, P.imagey))) return rc;
@@ -717,7 +733,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         for (int i = 0; i <= nside; i++) {
             if (i == nside && c->main_from >= levels) break;
             rtx_context::ShadowLane& sl = c->side[i == nside ? (int)rtx_context::kSide : i];
-            if (c->shadow_direct) continue;  // the table kernels read the hit records themselves: no queue, no sort buffers
+            const size_t qmark = c->allocs.size();
             if ((rc = c->dalloc(&sl.q.a, qcap))) return rc;
             if ((rc = c->dalloc(&sl.q.b, qcap))) return rc;
             if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
@@ -725,6 +741,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->dalloc(&sl.rank, qcap))) return rc;
             if ((rc = c->dalloc(&sl.bsum, (maxbins + 1023) / 1024))) return rc;
             if ((rc = c->dalloc(&sl.braw, (maxbins + 1023) / 1024))) return rc;
+            c->packet_allocs.insert(c->packet_allocs.end(), c->allocs.begin() + qmark, c->allocs.end());
         }
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * 2))) return rc;
@@ -743,6 +760,51 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         int nchunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         c->kev.resize((size_t)nchunks * levels * 2 * 2);  // (start, stop) x (closest, shadow) per generation and chunk
         for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
+    }
+    // ---- which form of the shadow stage this context runs: measured, not guessed -------------------------------------
+    // Two forms exist for the plain primitives and the affine spheres: the (light, cell) tables walked straight off the hit
+    // records (rtx_cells.hip.h) and the sorted queue traced by packets (k_shadow_pass).  Which is faster depends on how
+    // many casters a shadow ray's line meets (C4, 10,000 primitives: tables 3.1 against 4.2 ms; C5, 100,000 triangles in
+    // a box three times as deep: packets 100 against 135 ms), so a context whose chunks hold >= 2^18 primary rays renders
+    // its own frame twice in either form (the second one timed) and keeps the faster; the other form's buffers are freed.
+    // Smaller frames take the tables (the shorter chain of launches).  The images are the same either way.
+    {
+        int force = -1;
+#ifdef RTX_AB_KNOBS
+        if (const char* e = std::getenv("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;  // 0 packets, 1 tables
+#endif
+        const bool can_tables = c->use_cells && c->shadow_direct;
+        bool tables = can_tables;
+        if (can_tables && force < 0 && ntrace > 0 && (int64_t)c->chunk_rows * W >= ((int64_t)1 << 18) && c->S.nl > 0) {
+            float ms[2] = {0.0f, 0.0f};
+            for (int form = 0; form < 2; form++) {
+                c->use_cells = form == 1;
+                for (int it = 0; it < 2; it++)
+                    if ((rc = context_render_impl(c, nullptr, nullptr))) return rc;
+                HIPCHK(hipStreamSynchronize(nullptr));
+                HIPCHK(hipEventElapsedTime(&ms[form], c->ev0, c->ev1));
+            }
+            tables = ms[1] <= ms[0];
+            c->rendered = false;
+        } else if (force >= 0) {
+            tables = can_tables && force == 1;
+        }
+        if (tables) {
+            c->use_cells = true;
+            c->dfree_group(c->packet_allocs);
+            for (rtx_context::ShadowLane& sl : c->side) { sl.q = {}; sl.hist = sl.offs = sl.rank = sl.bsum = sl.braw = nullptr; }
+            c->S.aff_cells = nullptr;
+        } else if (c->cells.off && !can_tables && force != 0) {
+            // tables for the plain primitives but none for this scene's affine spheres: k_shadow_cells over the sorted
+            // queue, k_shadow_affine behind it -- everything stays
+            c->use_cells = true;
+            c->shadow_direct = false;
+        } else {
+            c->use_cells = false;  // packets: the tables go
+            c->shadow_direct = false;
+            c->dfree_group(c->table_allocs);
+            c->cells = CellTab{};
+        }
     }
     return RTX_OK;
 }
@@ -861,7 +923,7 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                     forked[k] = true;
                 }
                 int* sc = c->d_scnt + ((size_t)nchunks * levels + k);
-                if (!c->shadow_direct) {
+                if (!(c->use_cells && c->shadow_direct)) {
                     HIPCHK(hipMemsetAsync(sl.hist, 0, sizeof(int) * (size_t)c->nbins, ss));
                     hipLaunchKernelGGL(k_shadow_bin, dim3(g), dim3(kBlock), 0, ss, c->S, Lk, nodes + k, c->binG, sl.hist, sl.rank);
                     {
@@ -883,13 +945,13 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 // later generations take the pooled stages (rtx_shadow.hip.h, shadow_plain_pool)
                 const bool pool = k >= c->pool_from;
 #define RTX_SHADOW_ARGS dim3(gq), dim3(kBlock), 0, ss, c->S, sl.q, sc + 0, Lk.lit, Lk.cap, c->split4, c->split8
-                if (c->shadow_direct) {
+                if (c->use_cells && c->shadow_direct) {
                     // the whole shadow stage of this generation in ONE launch: every (hit, light) pair walks the tables
                     // (rtx_cells.hip.h) straight off the hit records -- no queue, no sort
                     const dim3 gd(g, (unsigned)c->S.nl);
                     if (exec) hipLaunchKernelGGL(k_shadow_direct<true>, gd, dim3(kBlock), 0, ss, c->S, c->cells, Lk, nodes + k);
                     else hipLaunchKernelGGL(k_shadow_direct<false>, gd, dim3(kBlock), 0, ss, c->S, c->cells, Lk, nodes + k);
-                } else if (c->cells.off) {
+                } else if (c->use_cells) {
                     // the sorted queue through the tables, one workgroup per 256 queue slots at every size; without an affine
                     // table the affine spheres behind it for the rays still lit
                     const dim3 gc(grid_for(live_cap * (size_t)c->S.nl + c->qpad));
@@ -1030,7 +1092,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM"})  // the A/B aids context creation reads
         if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }
