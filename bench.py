@@ -103,13 +103,15 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
             "traffic": None, "peak_no_fma": PEAK_FP32_NOFMA_TFLOPS, "frac_no_fma": None}
     if args.no_count:
         return roof
+    # the counting and the serial frames run the form of the shadow stage the timed context chose by measurement
+    form = F.F_SHADOW_TABLES if st_timed.shadow_form else F.F_SHADOW_PACKETS
     # (a) executed work, by kernel and kind (untimed frame, counting instantiations of the production kernels)
-    c = make_ctx(F.F_COUNT_EXEC)
+    c = make_ctx(F.F_COUNT_EXEC | form)
     c.render(stream, None)
     ex = c.stats().exec_dict()
     c.close()
     # (b) non-overlapped kernel times: serial frames, HIP events around every hot launch
-    c = make_ctx(F.F_SERIAL | F.F_TIME_KERNELS)
+    c = make_ctx(F.F_SERIAL | F.F_TIME_KERNELS | form)
     for _ in range(3):
         c.render(stream, None)
     ss = c.stats()
@@ -143,8 +145,9 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
                      "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.  "
                      "reference_test_flops / useful_frac = the same with only the reference's own tests credited (SURVEY.md 8d: sphere, "
                      "affine sphere, triangle; none of the culling tests in front of them).  "
-                     "k_shadow_pass = one timed bracket per generation: the table walk k_shadow_cells (plain spheres and triangles) plus "
-                     "the affine-sphere kernel k_shadow_affine behind it.")
+                     "k_shadow_pass = one timed bracket per generation: form 'tables' = ONE launch, k_shadow_direct (plain primitives and affine "
+                     "spheres through the (light, cell) tables, straight off the hit records); form 'packets' = the traversal kernel "
+                     "k_shadow_pass plus the affine-sphere kernel k_shadow_affine behind it, over the sorted queue.")
     # (c) what the reference's brute-force loops would execute for the same rays, and the exact-only kernels' own fraction
     bw, bh = (W, H) if args.workload != "c5" else (W // 16, H // 16)   # C5 brute force at full size is minutes per frame
     import rtxamd as rt_
@@ -180,11 +183,11 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
         src, rows = pmc_summary(args.workload)
         frames, tot_valu = None, 0.0
         # the timed bracket of a shadow generation holds the traversal kernel AND the affine-sphere kernel behind it
-        group = ("k_shadow_pass", "k_shadow_cells", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
+        group = ("k_shadow_pass", "k_shadow_cells", "k_shadow_direct", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
         acc = {}
         for row in rows:
             name = row["kernel"].replace("rtx::", "")
-            if name.startswith("k_affine_cells"):
+            if name.startswith(("k_affine_cells", "k_cells_", "k_aff_build")):   # context creation
                 continue
             if name.startswith("k_aa_quantise"):   # one per frame (the calibration pass at context creation has none)
                 frames = float(row["dispatches_per_pass"])
@@ -373,6 +376,7 @@ def main():
                        "parallelism": "scanline bands of %d rows, round-robin over %d GPU(s), RCCL gather of rgb8" % (args.band_rows, world)
                                       if world > 1 else "1 GPU, whole frame",
                        "serial_streams": bool(args.serial),
+                       "shadow_form": "tables" if st.shadow_form else "packets",
                        "rays_per_frame": {"primary": float(rays[0].item()), "secondary": float(rays[1].item()),
                                           "shadow": float(rays[2].item())}},
         }
@@ -383,6 +387,8 @@ def main():
     # ---- end to end at the C-ABI: untimed extras, N = 1 only ----
     if rank == 0 and world == 1:
         import numpy as np
+        ctx.render(stream, None)
+        ctx.read_rgb8()                            # (the context's pinned staging buffer is allocated by its first read)
         t0 = time.perf_counter()
         ctx.render(stream, None)
         img = ctx.read_rgb8()                      # waits for the frame, copies 3 B / pixel to the host
@@ -397,8 +403,9 @@ def main():
         out["end_to_end"] = {"resident_render_plus_d2h_ms": (t1 - t0) * 1e3, "one_shot_rtx_render_rgb8_first_call_ms": (t2 - t1) * 1e3,
                              "one_shot_rtx_render_rgb8_next_call_ms": (t3 - t2) * 1e3,
                              "note": "value above is the resident render with the frame left in HBM; these add the 24.9 MB device-to-host "
-                                     "copy (pageable host buffer), and for the one-shot drop-in call: context creation (scene pack + upload, "
-                                     "cell table, queue allocation, calibration pass) on its first call, a hash of the scene on the next"}
+                                     "copy (through the context's pinned staging buffer into the caller's pageable one), and for the one-shot drop-in call: "
+                                     "context creation (scene pack + upload, (light, cell) tables, queue allocation, calibration pass, the timed "
+                                     "choice between the two forms of the shadow stage) on its first call, a hash of the scene on the next"}
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 0x00030200u
+#define RTX_ABI_VERSION 0x00030300u
 
 /* ---- data contract: field-for-field the reference's PODs, so a host that keeps the ----------
  * ---- reference's std::vector<sphere> etc. can pass &v[0] with zero conversion.      ---------- */
@@ -134,6 +134,14 @@ typedef struct rtx_params {
                                    calibration pass measures at creation (A/B aid; same image) */
 #define RTX_F_NO_CACHE   1024u /* one-shot entry points (rtx_render_rgb8 / _f32): create and destroy a context inside the call instead of
                                    keeping the last one (see rtx_render_rgb8) */
+#define RTX_F_MULTI_ON_ONE_DEVICE 2048u /* test aid for one-GPU machines, rtx_render_rgb8 with ngpus > 1 only: every rank runs on ONE device (params->device,
+                                   or device 0) and the bands are gathered with device-to-device copies instead of RCCL, which refuses
+                                   two ranks on one device; everything else is the code a multi-GPU machine runs */
+#define RTX_F_SHADOW_TABLES  4096u /* the shadow stage has two forms with the same result: (light, direction cell) tables walked straight off the hit
+                                   records, and packets over a queue sorted by light and direction.  By default a context renders its own
+                                   frame in both forms at creation and keeps the faster (rtx_stats.shadow_form says which); these two flags
+                                   skip the measurement and take the tables (where the scene allows them) / the packets. */
+#define RTX_F_SHADOW_PACKETS 8192u
 #define RTX_F_COUNT_EXEC   64u  /* run the counting instantiations of the PRODUCTION intersection kernels (slower: atomics):
                                    what they actually evaluate, by kind -> rtx_stats.exec_counts.  Same image. */
 #define RTX_F_COUNT_TESTS   2u  /* run the counting variants of the two intersection kernels (slower):
@@ -183,6 +191,8 @@ typedef struct rtx_stats {
      * 9 ... that ran the three areas (:352-365), 10 polygon fan triangles tested, 11 packets built, 12 rays traced,
      * 13 exact triangle tests that left at the edge filter. */
     uint64_t exec_counts[3][RTX_EXEC_KINDS];
+    int32_t  shadow_form;       /* the form of the shadow stage this context runs: 1 tables, 0 packets (RTX_F_SHADOW_TABLES) */
+    int32_t  reserved0;
     uint64_t queue_overflow;    /* secondary rays dropped because a generation's queue was full, since the context was created.
                                    0 by construction: capacities are the worst case, or (scenes with primitives that both
                                    reflect and refract) measured by a calibration pass over the very frame the context renders */

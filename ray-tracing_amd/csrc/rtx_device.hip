@@ -47,6 +47,14 @@ namespace rtx {
 
 static thread_local std::string g_last_hip_error;
 
+// A/B aids (tools/dbg): environment variables that move a threshold or force a kernel form -- compiled in only with
+// -DRTX_AB_KNOBS (make EXTRA=-DRTX_AB_KNOBS).  The shipped library reads no environment at all.
+#ifdef RTX_AB_KNOBS
+static inline const char* ab_knob(const char* name) { return std::getenv(name); }
+#else
+static inline const char* ab_knob(const char*) { return nullptr; }
+#endif
+
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -142,6 +150,7 @@ struct rtx_context {
     std::vector<void*> table_allocs, packet_allocs;  // what only one of the two forms needs (the other's is freed once the form is chosen)
     int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
                                             // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
+    uint8_t* h_stage = nullptr;             // pinned host staging of rtx_context_read_rgb8 (allocated on its first call; not in arena mode)
     unsigned char* last_dst = nullptr;      // where the last render put its rgb8 rows (d_rgb8 or the caller's buffer)
     bool rendered = false;
     int nchunks = 0;
@@ -220,8 +229,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->device = dev;
     c->params = *params;
     c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
-    if (const char* e4 = std::getenv("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
-    if (const char* e8 = std::getenv("RTX_SPLIT8")) c->split8 = std::atoi(e8);
+    if (const char* e4 = ab_knob("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
+    if (const char* e8 = ab_knob("RTX_SPLIT8")) c->split8 = std::atoi(e8);
     c->width = params->width;
     c->height = params->height;
     const int W = c->width, H = c->height;
@@ -386,9 +395,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         // before the count) and not for the exact-only / counting frames, which trace no culled shadow rays.
         c->cells = CellTab{};
         bool want_cells = !c->arena && c->S.nl > 0 && c->S.sncl > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
-#ifdef RTX_AB_KNOBS
-        if (const char* e = std::getenv("RTX_CELLS")) want_cells = want_cells && std::atoi(e) != 0;
-#endif
+        if (const char* e = ab_knob("RTX_CELLS")) want_cells = want_cells && std::atoi(e) != 0;
         if (want_cells) {
             // The tables' range: the far corner of the box of the shadow casters themselves (an affine sphere as it sits for a
             // shadow ray: its centre and radius as given, raytracing.cpp:571-576), twice over -- not of every bounded
@@ -419,9 +426,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             float* d_dc = nullptr;
             if ((rc = c->upload(&d_dc, dc))) return rc;
             int G0 = 512;
-#ifdef RTX_AB_KNOBS
-            if (const char* e = std::getenv("RTX_CELL_G")) G0 = std::max(8, std::min(4096, std::atoi(e)));
-#endif
+            if (const char* e = ab_knob("RTX_CELL_G")) G0 = std::max(8, std::min(4096, std::atoi(e)));
             while ((size_t)c->S.nl * G0 * G0 > ((size_t)1 << 24) && G0 > 8) G0 /= 2;
             // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
@@ -490,9 +495,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->table_allocs.assign(c->allocs.begin() + tab_mark, c->allocs.end());
             c->use_cells = c->cells.off != nullptr;
             c->shadow_direct = c->cells.off && (c->S.naff == 0 || c->cells.aoff);
-#ifdef RTX_AB_KNOBS
-            if (const char* e = std::getenv("RTX_SHADOW_DIRECT")) c->shadow_direct = c->shadow_direct && std::atoi(e) != 0;
-#endif
+            if (const char* e = ab_knob("RTX_SHADOW_DIRECT")) c->shadow_direct = c->shadow_direct && std::atoi(e) != 0;
         }
         c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
         const size_t bitmask_mark = c->allocs.size();
@@ -553,7 +556,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if ((int64_t)ntrace * W >= (int64_t)24 << 20) c->binG = 512;
         if (c->S.nsb >= 32768) c->binG = 1024;
     }
-    if (const char* bg = std::getenv("RTX_BIN_G")) c->binG = std::max(8, std::min(4096, std::atoi(bg)));  // A/B aid (same image)
+    if (const char* bg = ab_knob("RTX_BIN_G")) c->binG = std::max(8, std::min(4096, std::atoi(bg)));  // A/B aid (same image)
     while (nl1 * c->binG * c->binG > ((size_t)1 << 24) && c->binG > 8) c->binG /= 2;
     c->nbins = (int)nl1 * c->binG * c->binG;
     c->qpad = (size_t)64 * ((size_t)(c->nbins + 1023) / 1024 + 1);
@@ -717,12 +720,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     // of the 4K frame -- are bound by a wave's chain of dependent steps, which the extra level lengthens.  RTX_TWO_LEVEL=0/1
     // forces it (A/B aid; same image).
     c->S.sel2 = ((int64_t)rows * W >= ((int64_t)1 << 22)) ? 1 : 0;
-    if (const char* e2 = std::getenv("RTX_TWO_LEVEL")) c->S.sel2 = std::atoi(e2) ? 1 : 0;
+    if (const char* e2 = ab_knob("RTX_TWO_LEVEL")) c->S.sel2 = std::atoi(e2) ? 1 : 0;
     // Generation 0's shadow rays take the walk when they fill the chip and the pooled stages when they do not (chunks of
     // <= 3 * 2^20 primary rays: a rank's share of 4 or 8 of the 4K frame, halo rows included; measured 1.20 -> 1.04 ms for a rank of 8, 1.59 -> 1.55
     // for a rank of 4, 2.59 -> 2.67 for a rank of 2, 4.03 -> 4.18 for the whole frame).
     if ((int64_t)rows * W <= ((int64_t)3 << 20)) c->pool_from = 0;
-    if (const char* pf = std::getenv("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
+    if (const char* pf = ab_knob("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
     if ((rc = alloc_levels(caps, true))) return rc;
     {   // shadow-ray queues: the largest generation's hits x lights
         size_t mx = 0;
@@ -770,9 +773,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     // Smaller frames take the tables (the shorter chain of launches).  The images are the same either way.
     {
         int force = -1;
-#ifdef RTX_AB_KNOBS
-        if (const char* e = std::getenv("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;  // 0 packets, 1 tables
-#endif
+        if (params->flags & RTX_F_SHADOW_PACKETS) force = 0;
+        if (params->flags & RTX_F_SHADOW_TABLES) force = 1;
+        if (const char* e = ab_knob("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;  // 0 packets, 1 tables
         const bool can_tables = c->use_cells && c->shadow_direct;
         bool tables = can_tables;
         if (can_tables && force < 0 && ntrace > 0 && (int64_t)c->chunk_rows * W >= ((int64_t)1 << 18) && c->S.nl > 0) {
@@ -1029,6 +1032,7 @@ static int context_stats_impl(rtx_context* c, rtx_stats* s)
     }
     s->chunks = c->nchunks;
     s->levels = c->levels;
+    s->shadow_form = c->use_cells ? 1 : 0;
     float ms = 0;
     if (c->ev0 && c->ev1) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));  // arena mode keeps no events: 0
     s->ms_total = ms;
@@ -1093,7 +1097,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
     for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM"})  // the A/B aids context creation reads
-        if (const char* v = std::getenv(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
+        if (const char* v = ab_knob(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }
 
@@ -1140,7 +1144,7 @@ static int render_one(const rtx_scene* scene, const rtx_params* params, uint8_t*
 // the fan-in is point to point, not a ring), one device-to-host copy of the gathered bands, rows put in place.
 // RCCL is loaded on first use (dlopen: the library does not depend on it at load time, and a process that already
 // holds an RCCL -- PyTorch's -- shares it); failing that: RTX_E_RCCL.
-// RTX_MULTI_ON_ONE_DEVICE=1 (test aid for one-GPU machines): the ranks all run on device 0 and the exchange is
+// RTX_F_MULTI_ON_ONE_DEVICE (test aid for one-GPU machines): the ranks all run on one device and the exchange is
 // device-to-device copies instead of RCCL (which refuses two ranks on one device); everything else is the same code.
 // ------------------------------------------------------------------------------------------------
 struct Rccl {
@@ -1196,50 +1200,72 @@ static Rccl& rccl()
         }                                                                                     \
     } while (0)
 
-static int render_multi(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
+// The multi-device form keeps what it built -- one context and one stream per device, the RCCL communicators, the
+// gather buffer on device 0 and its pinned host staging -- between calls that read the same bytes (the one-shot cache's
+// 128-bit hash, plus the device count): ncclCommInitAll and N context creations are hundreds of ms around a frame of a
+// millisecond.  rtx_release_cached_context() frees it, RTX_F_NO_CACHE never keeps it, a failed call drops it.
+struct MultiCache {
+    std::mutex m;
+    bool valid = false;
+    uint64_t key[2] = {0, 0};
+    int G = 0;
+    bool on_one = false;
+    std::vector<rtx_context*> ctx;
+    std::vector<hipStream_t> stream;
+    std::vector<int> dev;
+    std::vector<std::vector<int32_t>> rows;
+    std::vector<ncclComm_t> comms;
+    bool have_comms = false;
+    unsigned char* d_gather = nullptr;   // on device 0: G slots of `slot` bytes, slot g = rank g's packed rows
+    uint8_t* h_gather = nullptr;         // pinned
+    size_t slot = 0;
+    void release()
+    {
+        if (have_comms)
+            for (ncclComm_t cm : comms)
+                if (cm) (void)rccl().CommDestroy(cm);
+        for (size_t g = 0; g < ctx.size(); g++) {
+            if (ctx[g]) rtx_context_destroy(ctx[g]);
+            if (g < stream.size() && stream[g]) { (void)hipSetDevice(dev[g]); (void)hipStreamDestroy(stream[g]); }
+        }
+        if (d_gather) { (void)hipSetDevice(dev.empty() ? 0 : dev[0]); (void)hipFree(d_gather); }
+        if (h_gather) (void)hipHostFree(h_gather);
+        ctx.clear(); stream.clear(); dev.clear(); rows.clear(); comms.clear();
+        have_comms = false; d_gather = nullptr; h_gather = nullptr; slot = 0; valid = false; G = 0;
+    }
+};
+static MultiCache g_multi;
+
+static int multi_create(MultiCache& M, const rtx_scene* scene, const rtx_params* params, int G, bool on_one)
 {
-    const int ndev = rtx_device_count();
-    if (ndev <= 0) return RTX_E_NO_DEVICE;
-    const char* one = std::getenv("RTX_MULTI_ON_ONE_DEVICE");
-    const bool on_one = one && one[0] == '1';
-    if (!on_one && ngpus > ndev) ngpus = ndev;
-    if (ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
-    if (ngpus > 64) ngpus = 64;
-    const int G = ngpus;
     const size_t rowb = (size_t)params->width * 3;
     const int band = params->band_rows > 0 ? params->band_rows : 16;
-
     int rc = RTX_OK;
-    std::vector<rtx_context*> ctx(G, nullptr);
-    std::vector<hipStream_t> stream(G, nullptr);
-    std::vector<int> dev(G), rcs(G, 0);
+    M.G = G; M.on_one = on_one;
+    M.ctx.assign(G, nullptr); M.stream.assign(G, nullptr); M.dev.assign(G, 0); M.rows.assign(G, {}); M.comms.assign(G, nullptr);
+    std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
-    std::vector<std::vector<int32_t>> rows(G);
-    std::vector<ncclComm_t> comms(G, nullptr);
-    unsigned char* d_gather = nullptr;   // on device 0: G slots of `slot` bytes, slot g = rank g's packed rows
-    std::vector<uint8_t> host;
     size_t slot = 0;
-    bool have_comms = false;
     for (int g = 0; g < G; g++) {
-        dev[g] = on_one ? 0 : g;
+        M.dev[g] = on_one ? (params->device >= 0 ? params->device : 0) : g;
         int n = rtx_band_rows(params->height, G, g, band, nullptr, 0);
         if (n < 0) return n;
-        rows[g].resize(n);
-        if (n) rtx_band_rows(params->height, G, g, band, rows[g].data(), n);
+        M.rows[g].resize(n);
+        if (n) rtx_band_rows(params->height, G, g, band, M.rows[g].data(), n);
         slot = std::max(slot, (size_t)n * rowb);
     }
-    slot = (slot + 255) & ~(size_t)255;
-
+    M.slot = (slot + 255) & ~(size_t)255;
     {   // one context per device, created concurrently (scene packing and upload are per device)
         std::vector<std::thread> th;
         for (int g = 0; g < G; g++)
             th.emplace_back([&, g]() {
                 try {
-                    if (rows[g].empty()) return;
+                    if (M.rows[g].empty()) return;
                     rtx_params p = *params;
-                    p.nranks = G; p.rank = g; p.device = dev[g]; p.band_rows = band;
-                    rcs[g] = rtx_context_create(scene, &p, &ctx[g]);
-                    if (!rcs[g] && hipStreamCreateWithFlags(&stream[g], hipStreamNonBlocking) != hipSuccess) rcs[g] = RTX_E_HIP;
+                    p.nranks = G; p.rank = g; p.device = M.dev[g]; p.band_rows = band;
+                    p.flags &= ~(uint32_t)(RTX_F_MULTI_ON_ONE_DEVICE | RTX_F_NO_CACHE);
+                    rcs[g] = rtx_context_create(scene, &p, &M.ctx[g]);
+                    if (!rcs[g] && hipStreamCreateWithFlags(&M.stream[g], hipStreamNonBlocking) != hipSuccess) rcs[g] = RTX_E_HIP;
                 } catch (const std::bad_alloc&) { rcs[g] = RTX_E_OOM; }
                 catch (...) { rcs[g] = RTX_E_HIP; }
                 if (rcs[g]) errs[g] = g_last_hip_error;  // the worker's own thread-local text
@@ -1247,57 +1273,72 @@ static int render_multi(const rtx_scene* scene, const rtx_params* params, int ng
         for (auto& t : th) t.join();
     }
     for (int g = 0; g < G; g++)
-        if (rcs[g]) { rc = rcs[g]; g_last_hip_error = "device " + std::to_string(dev[g]) + ": " + errs[g]; goto done; }
-
-    HIPCHK_GOTO(hipSetDevice(dev[0]));
-    HIPCHK_GOTO(hipMalloc((void**)&d_gather, slot * (size_t)G));
-    if (!stream[0]) HIPCHK_GOTO(hipStreamCreateWithFlags(&stream[0], hipStreamNonBlocking));
+        if (rcs[g]) { g_last_hip_error = "device " + std::to_string(M.dev[g]) + ": " + errs[g]; return rcs[g]; }
+    HIPCHK(hipSetDevice(M.dev[0]));
+    HIPCHK(hipMalloc((void**)&M.d_gather, M.slot * (size_t)G));
+    HIPCHK(hipHostMalloc((void**)&M.h_gather, M.slot * (size_t)G, hipHostMallocDefault));
+    if (!M.stream[0]) HIPCHK(hipStreamCreateWithFlags(&M.stream[0], hipStreamNonBlocking));
     if (!on_one) {
-        if (!rccl().ok) { g_last_hip_error = "librccl.so could not be loaded (dlopen)"; rc = RTX_E_RCCL; goto done; }
-        NCCLCHK(rccl().CommInitAll(comms.data(), G, dev.data()));
-        have_comms = true;
+        if (!rccl().ok) { g_last_hip_error = "librccl.so could not be loaded (dlopen)"; return RTX_E_RCCL; }
+        ncclResult_t r = rccl().CommInitAll(M.comms.data(), G, M.dev.data());
+        if (r != ncclSuccess) { g_last_hip_error = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r); return RTX_E_RCCL; }
+        M.have_comms = true;
     }
+    (void)rc;
+    return RTX_OK;
+}
+
+static int multi_frame(MultiCache& M, const rtx_params* params, uint8_t* out, rtx_stats* stats)
+{
+    const int G = M.G;
+    const size_t rowb = (size_t)params->width * 3;
+    int rc = RTX_OK;
+    bool in_group = false;
     // every rank renders into the buffer its band is sent from: rank 0 straight into its slot of the gather buffer
     for (int g = 0; g < G; g++) {
-        if (!ctx[g]) continue;
-        int r = rtx_context_render(ctx[g], stream[g], g == 0 ? d_gather : nullptr);
+        if (!M.ctx[g]) continue;
+        int r = rtx_context_render(M.ctx[g], M.stream[g], g == 0 ? M.d_gather : nullptr);
         if (r) { rc = r; goto done; }
     }
-    if (!on_one) {
+    if (!M.on_one) {
+        // RCCL behind the C-ABI: "parity unpinned" until a machine with >= 2 GPUs has run it (every box so far had one)
         NCCLCHK(rccl().GroupStart());
+        in_group = true;
         for (int g = 1; g < G; g++) {
-            if (!ctx[g]) continue;
-            const size_t bytes = rows[g].size() * rowb;
-            HIPCHK_GOTO(hipSetDevice(dev[g]));
-            NCCLCHK(rccl().Send(ctx[g]->d_rgb8, bytes, ncclUint8, 0, comms[g], stream[g]));
-            HIPCHK_GOTO(hipSetDevice(dev[0]));
-            NCCLCHK(rccl().Recv(d_gather + (size_t)g * slot, bytes, ncclUint8, g, comms[0], stream[0]));
+            if (!M.ctx[g]) continue;
+            const size_t bytes = M.rows[g].size() * rowb;
+            HIPCHK_GOTO(hipSetDevice(M.dev[g]));
+            NCCLCHK(rccl().Send(M.ctx[g]->d_rgb8, bytes, ncclUint8, 0, M.comms[g], M.stream[g]));
+            HIPCHK_GOTO(hipSetDevice(M.dev[0]));
+            NCCLCHK(rccl().Recv(M.d_gather + (size_t)g * M.slot, bytes, ncclUint8, g, M.comms[0], M.stream[0]));
         }
+        in_group = false;
         NCCLCHK(rccl().GroupEnd());
     } else {
         for (int g = 1; g < G; g++) {
-            if (!ctx[g]) continue;
-            HIPCHK_GOTO(hipMemcpyAsync(d_gather + (size_t)g * slot, ctx[g]->d_rgb8, rows[g].size() * rowb, hipMemcpyDeviceToDevice, stream[g]));
+            if (!M.ctx[g]) continue;
+            HIPCHK_GOTO(hipSetDevice(M.dev[g]));
+            HIPCHK_GOTO(hipMemcpyAsync(M.d_gather + (size_t)g * M.slot, M.ctx[g]->d_rgb8, M.rows[g].size() * rowb, hipMemcpyDeviceToDevice, M.stream[g]));
         }
     }
-    for (int g = G - 1; g >= 0; g--) {
-        if (!stream[g]) continue;
-        HIPCHK_GOTO(hipSetDevice(dev[g]));
-        HIPCHK_GOTO(hipStreamSynchronize(stream[g]));
+    for (int g = G - 1; g >= 1; g--) {
+        if (!M.stream[g]) continue;
+        HIPCHK_GOTO(hipSetDevice(M.dev[g]));
+        HIPCHK_GOTO(hipStreamSynchronize(M.stream[g]));
     }
-    // ONE device-to-host copy of the gathered bands, then the rows go to their places in the caller's frame
-    host.resize(slot * (size_t)G);
-    HIPCHK_GOTO(hipSetDevice(dev[0]));
-    HIPCHK_GOTO(hipMemcpy(host.data(), d_gather, host.size(), hipMemcpyDeviceToHost));
+    // ONE device-to-host copy of the gathered bands (pinned staging), then the rows go to their places in the caller's frame
+    HIPCHK_GOTO(hipSetDevice(M.dev[0]));
+    HIPCHK_GOTO(hipMemcpyAsync(M.h_gather, M.d_gather, M.slot * (size_t)G, hipMemcpyDeviceToHost, M.stream[0]));
+    HIPCHK_GOTO(hipStreamSynchronize(M.stream[0]));
     for (int g = 0; g < G; g++)
-        for (size_t r = 0; r < rows[g].size(); r++)
-            std::memcpy(out + (size_t)rows[g][r] * rowb, host.data() + (size_t)g * slot + r * rowb, rowb);
+        for (size_t r = 0; r < M.rows[g].size(); r++)
+            std::memcpy(out + (size_t)M.rows[g][r] * rowb, M.h_gather + (size_t)g * M.slot + r * rowb, rowb);
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         for (int g = 0; g < G; g++) {
-            if (!ctx[g]) continue;
+            if (!M.ctx[g]) continue;
             rtx_stats s;
-            int r = rtx_context_stats(ctx[g], &s);
+            int r = rtx_context_stats(M.ctx[g], &s);
             if (r) { rc = r; goto done; }
             stats->rays_primary += s.rays_primary; stats->rays_secondary += s.rays_secondary;
             stats->rays_shadow += s.rays_shadow; stats->hits += s.hits;
@@ -1309,16 +1350,38 @@ static int render_multi(const rtx_scene* scene, const rtx_params* params, int ng
         }
     }
 done:
-    {
+    if (in_group) {  // a Send / Recv / hipSetDevice failed inside the group: close it before anything else touches RCCL
         const std::string keep = g_last_hip_error;
-        if (have_comms)
-            for (int g = 0; g < G; g++)
-                if (comms[g]) (void)rccl().CommDestroy(comms[g]);
-        for (int g = 0; g < G; g++) {
-            if (ctx[g]) rtx_context_destroy(ctx[g]);
-            if (stream[g]) { (void)hipSetDevice(dev[g]); (void)hipStreamDestroy(stream[g]); }
-        }
-        if (d_gather) { (void)hipSetDevice(dev[0]); (void)hipFree(d_gather); }
+        (void)rccl().GroupEnd();
+        g_last_hip_error = keep;
+    }
+    return rc;
+}
+
+static int render_multi(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)
+{
+    const int ndev = rtx_device_count();
+    if (ndev <= 0) return RTX_E_NO_DEVICE;
+    const bool on_one = (params->flags & RTX_F_MULTI_ON_ONE_DEVICE) != 0;
+    if (!on_one && ngpus > ndev) ngpus = ndev;
+    if (ngpus <= 1) return render_one(scene, params, out, nullptr, stats);
+    if (ngpus > 64) ngpus = 64;
+    uint64_t key[2];
+    hash_call(scene, params, -1 - ngpus, key);
+    std::lock_guard<std::mutex> lk(g_multi.m);
+    MultiCache& M = g_multi;
+    int rc = RTX_OK;
+    if (!M.valid || M.key[0] != key[0] || M.key[1] != key[1] || M.G != ngpus || M.on_one != on_one) {
+        M.release();
+        rc = multi_create(M, scene, params, ngpus, on_one);
+        if (rc) { const std::string keep = g_last_hip_error; M.release(); g_last_hip_error = keep; return rc; }
+        M.key[0] = key[0]; M.key[1] = key[1];
+        M.valid = true;
+    }
+    rc = multi_frame(M, params, out, stats);
+    if (rc || (params->flags & RTX_F_NO_CACHE)) {
+        const std::string keep = g_last_hip_error;
+        M.release();
         if (rc) g_last_hip_error = keep;
     }
     return rc;
@@ -1398,6 +1461,7 @@ void rtx_context_destroy(rtx_context* c)
         for (rtx_context::ShadowLane& sl : c->side)
             if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     }
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (!c->allocs.empty() || c->ev0 || c->ev1 || !c->kev.empty() || !c->ev_fork.empty()) {
         (void)hipSetDevice(c->device);
         for (void* p : c->allocs) (void)hipFree(p);
@@ -1438,9 +1502,38 @@ int rtx_context_read_rgb8(rtx_context* c, uint8_t* host)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     size_t n = c->own_rows.size() * (size_t)c->width * 3;
-    // the last frame's rows: in the context's own framebuffer, or in the device buffer the caller gave that render
-    if (n) HIPCHK(hipMemcpy(host, c->last_dst, n, hipMemcpyDeviceToHost));
-    return RTX_OK;
+    // the last frame's rows: in the context's own framebuffer, or in the device buffer the caller gave that render.
+    // Through a pinned staging buffer kept by the context: a copy into the caller's pageable memory runs at a third of the
+    // link's rate (3.2 ms for a 4K frame); pinned it takes 0.5 ms, and four host threads move it on in under a millisecond.
+    if (!n) return RTX_OK;
+    if (!c->arena && !c->h_stage && n >= ((size_t)1 << 20)) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, n, hipHostMallocDefault) == hipSuccess) c->h_stage = static_cast<uint8_t*>(q);
+        else (void)hipGetLastError();  // no pinned memory to be had: the plain copy below
+    }
+    if (!c->h_stage) {
+        HIPCHK(hipMemcpy(host, c->last_dst, n, hipMemcpyDeviceToHost));
+        return RTX_OK;
+    }
+    constexpr int kParts = 4;
+    const size_t part = ((n + kParts - 1) / kParts + 63) & ~(size_t)63;
+    // part p is copied to the host while part p - 1 is moved on by a thread of its own
+    std::thread th[kParts];
+    int started = 0, rc = RTX_OK;
+    for (int p = 0; p < kParts && !rc; p++) {
+        const size_t o0 = std::min(n, (size_t)p * part), o1 = std::min(n, o0 + part);
+        if (o1 == o0) break;
+        if (hipMemcpyAsync(c->h_stage + o0, c->last_dst + o0, o1 - o0, hipMemcpyDeviceToHost, c->last_stream) != hipSuccess ||
+            hipStreamSynchronize(c->last_stream) != hipSuccess) {
+            g_last_hip_error = std::string("rtx_context_read_rgb8: ") + hipGetErrorString(hipGetLastError());
+            rc = RTX_E_HIP;
+            break;
+        }
+        try { th[started] = std::thread([=]() { std::memcpy(host + o0, c->h_stage + o0, o1 - o0); }); started++; }
+        catch (...) { std::memcpy(host + o0, c->h_stage + o0, o1 - o0); }  // no thread to be had: move it on here
+    }
+    for (int p = 0; p < started; p++) th[p].join();
+    return rc;
 }
 
 int rtx_context_read_f32(rtx_context* c, float* host)
@@ -1512,8 +1605,12 @@ int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params, ui
 
 void rtx_release_cached_context(void)
 {
-    std::lock_guard<std::mutex> lk(g_one_shot.m);
-    if (g_one_shot.c) { rtx_context_destroy(g_one_shot.c); g_one_shot.c = nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_one_shot.m);
+        if (g_one_shot.c) { rtx_context_destroy(g_one_shot.c); g_one_shot.c = nullptr; }
+    }
+    std::lock_guard<std::mutex> lk(g_multi.m);
+    g_multi.release();
 }
 
 int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus, uint8_t* out, rtx_stats* stats)

@@ -19,6 +19,9 @@ F_TRACE_PLANES = 128
 F_TRI_MOLLER_TRUMBORE = 256
 F_WORST_CASE_QUEUES = 512
 F_NO_CACHE = 1024
+F_MULTI_ON_ONE_DEVICE = 2048
+F_SHADOW_TABLES = 4096
+F_SHADOW_PACKETS = 8192
 RTX_EXEC_KINDS = 16
 EXEC_KERNELS = ("k_closest_f", "k_closest_lanes", "k_shadow_pass")
 EXEC_KINDS = ("packet", "cone", "filt", "afilt", "strip", "sph", "sphx", "tri_early", "tri_cull", "tri_full", "poly", "packets_built", "rays", "tri_edge")
@@ -101,7 +104,8 @@ class Stats(C.Structure):
                 ("packet_stats", C.c_uint64 * 8),
                 ("launches_closest", C.c_int32), ("launches_shadow", C.c_int32),
                 ("ms_closest_lanes", C.c_float), ("launches_closest_lanes", C.c_int32),
-                ("exec_counts", (C.c_uint64 * RTX_EXEC_KINDS) * 3), ("queue_overflow", C.c_uint64)]
+                ("exec_counts", (C.c_uint64 * RTX_EXEC_KINDS) * 3),
+                ("shadow_form", C.c_int32), ("reserved0", C.c_int32), ("queue_overflow", C.c_uint64)]
 
     def exec_dict(self):
         """{kernel: {kind: count}} of the RTX_F_COUNT_EXEC counters."""

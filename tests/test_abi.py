@@ -37,7 +37,7 @@ def test_struct_layouts_match_reference(rt):
 
 def test_abi_version_and_errors(rt):
     L = rt.lib()
-    assert L.rtx_abi_version() == 0x00030200  # 3.0: capacities on the diagnostic entry points, rtx_render_rgb8_noalloc, executed-work counters in rtx_stats; 3.1: rtx_release_cached_context, RTX_F_NO_CACHE; 3.2: rtx_cluster_records
+    assert L.rtx_abi_version() == 0x00030300  # 3.3: rtx_stats.shadow_form, RTX_F_SHADOW_TABLES / _PACKETS, RTX_F_MULTI_ON_ONE_DEVICE; 3.0: capacities on the diagnostic entry points, rtx_render_rgb8_noalloc, executed-work counters in rtx_stats; 3.1: rtx_release_cached_context, RTX_F_NO_CACHE; 3.2: rtx_cluster_records
     assert b"no HIP device" in L.rtx_strerror(-2)
     assert L.rtx_strerror(0) == b"ok"
 

@@ -6,7 +6,8 @@ import rtxamd as rt
 p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
 rt.scenegen.write_c4(p)
 sc = rt.load_scene(p)
-ctx = rt.Context(sc, rt.Params.make(3840, 2160, 4))
+# the form the measured choice takes for this frame (bench.py: config.shadow_form), forced so that no timing frames of the other form run under the counters
+ctx = rt.Context(sc, rt.Params.make(3840, 2160, 4, flags=rt.host.F_SHADOW_TABLES))
 for _ in range(8):
     ctx.render()
 print(ctx.stats().ms_total)

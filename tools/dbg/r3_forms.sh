@@ -5,9 +5,8 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python -u -m pytest tests/ -m gpu -x -q --timeout 300 --timeout-method thread > $R/f_tests.log 2>&1 || { tail -30 $R/f_tests.log; exit 1; }
 tail -2 $R/f_tests.log
 for wl in c4 c5; do
-for form in 0 1 auto; do
-if [ $form = auto ]; then unset RTX_SHADOW_FORM; else export RTX_SHADOW_FORM=$form; fi
-timeout -k 10 300 python -u tools/dbg/ab.py 0 $wl > $R/f_${wl}_$form.log 2>&1 || { tail -5 $R/f_${wl}_$form.log; exit 1; }
-echo "$wl form=$form: $(cat $R/f_${wl}_$form.log)"
+for form in 8192 4096 0; do
+timeout -k 10 300 python -u tools/dbg/ab.py $form $wl > $R/f_${wl}_$form.log 2>&1 || { tail -5 $R/f_${wl}_$form.log; exit 1; }
+echo "$wl flags=$form (8192 packets, 4096 tables, 0 measured): $(cat $R/f_${wl}_$form.log)"
 done
 done
