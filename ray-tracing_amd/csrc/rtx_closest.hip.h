@@ -676,16 +676,16 @@ __device__ __forceinline__ void lex_update(LexAcc& h, int k, float t, int kind)
 // ------------------------------------------------------------------------------------------------
 constexpr int kPoolPrimBits = 26;  // (ray, primitive) entries: primitive | ray << 26 (rtx_context_create checks the scene fits)
 constexpr int kPoolB = 512;        // (ray, cluster) pairs of one round: R * clusters per round
+constexpr int kPoolQMax = 128;     // clusters per round at most (their spheres are staged in LDS)
 constexpr int kPoolC = 64 + 64;    // (ray, cluster, group) entries: fewer than 64 wait, one push adds up to 64
 constexpr int kPoolD = 64 + 64;    // (ray, primitive) entries: the same
 
 struct PoolLds {
-    float4 rayO[64];               // origin, w = flag bits (1 live, 2 abnormal)
-    float4 rayN[64];               // normalised direction
-    float4 rayD[64];               // direction as stored (the exact tests take both)
-    float4 csph[32];               // this round's cluster spheres { c, R }
-    int ccid[32];
-    unsigned short listB[kPoolB];  // ray << 5 | cluster slot of the round
+    float4 ray[3 * 64];            // R rays: [0, R) origin, w = flag bits (1 live, 2 abnormal); [R, 2R) normalised direction;
+                                   // [2R, 3R) direction as stored (the exact tests take both).  R = 4: [64, 192) holds the round's 128 cluster spheres
+    float4 csph[32];               // this round's cluster spheres { c, R } (R >= 16)
+    int ccid[kPoolQMax];
+    unsigned short listB[kPoolB];  // ray << 7 | cluster slot of the round
     unsigned int listC[kPoolC];    // cluster << 9 | ray << 3 | group
     unsigned int listD[kPoolD];    // ray << 26 | primitive
     int slot[64];                  // E: which lane delivers to ray r this step (-1 none)
@@ -708,9 +708,12 @@ template <int R>
 __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& L, const int n, const int q0, PoolLds& W, Exec* ex)
 {
     constexpr int kPer = 64 / R;                                  // lanes per ray in stage A
-    constexpr int kPoolQ = (kPoolB / R < 32) ? kPoolB / R : 32;   // clusters per round
+    constexpr int kPoolQ = (kPoolB / R < kPoolQMax) ? kPoolB / R : kPoolQMax;   // clusters per round: 8 (R = 64), 32 (R = 16), 128 (R = 4)
     const int lane = threadIdx.x & 63;
     const int myray = lane & (R - 1), part = lane / R;
+    float4* const rayO = W.ray; float4* const rayN = W.ray + R; float4* const rayD = W.ray + 2 * R;
+    float4* const csph = (R * 3 <= 64 && kPoolQ > 32) ? W.ray + 64 : W.csph;
+    static_assert(kPoolQ <= 32 || (R * 3 <= 64 && kPoolQ <= 128), "the round's cluster spheres fit their LDS");
     // ---- the wave's rays: lanes < R own one each ----
     const int q = q0 + lane;
     const bool inq = lane < R && q < n;
@@ -722,13 +725,13 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     const bool abn = live && ray_abnormal(o, d, nd, S.guard);
     if (inq) ex_add(ex, EX_RAYS);
     if (lane < R) {
-        W.rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
-        W.rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-        W.rayD[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+        rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
+        rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+        rayD[lane] = make_float4(d.x, d.y, d.z, 0.0f);
     }
     W.slot[lane] = -1;
     lds_fence();
-    const float4 aO = W.rayO[myray], aN = W.rayN[myray];  // stage A's ray of this lane
+    const float4 aO = rayO[myray], aN = rayN[myray];  // stage A's ray of this lane
     const F3 ao = f3(aO.x, aO.y, aO.z), an = f3(aN.x, aN.y, aN.z);
     const bool alive = (__float_as_int(aO.w) & 1) != 0, aabn = (__float_as_int(aO.w) & 2) != 0;
     LexAcc h;
@@ -761,7 +764,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         const unsigned e = W.listD[base + (has ? lane : 0)];
         const int k = (int)(e & ((1u << kPoolPrimBits) - 1u));
         const int rr = (int)(e >> kPoolPrimBits);
-        const float4 rO = W.rayO[rr], rN = W.rayN[rr], rD = W.rayD[rr];
+        const float4 rO = rayO[rr], rN = rayN[rr], rD = rayD[rr];
         float t = 0.0f;
         int kind = 0;
         if (has) kind = exact_hit(S, k, f3(rO.x, rO.y, rO.z), f3(rD.x, rD.y, rD.z), f3(rN.x, rN.y, rN.z), t, ex);
@@ -781,7 +784,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         for (int v = 0; v < kGroup; v++) mb[v] = S.cmem[m + v];
         const int4 k0 = *reinterpret_cast<const int4*>(S.cidx + m), k1 = *reinterpret_cast<const int4*>(S.cidx + m + 4);
         const int kk[kGroup] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
-        const float4 rO = W.rayO[rr], rN = W.rayN[rr];
+        const float4 rO = rayO[rr], rN = rayN[rr];
         const bool use = (__float_as_int(rO.w) & 2) == 0;
         const F3 fo = use ? f3(rO.x, rO.y, rO.z) : f3(1e18f, 0.0f, 0.0f);
         const F3 fd = use ? f3(rN.x * kDirScale, rN.y * kDirScale, rN.z * kDirScale) : f3(0.0f, 0.0f, 0.0f);
@@ -809,13 +812,13 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     auto run_B = [&](int base, int cnt) {
         const bool has = lane < cnt;
         const unsigned e = W.listB[base + (has ? lane : 0)];
-        const int rr = (int)(e >> 5);
-        const int cid = W.ccid[e & 31u];
+        const int rr = (int)(e >> 7);
+        const int cid = W.ccid[e & 127u];
         const float4* srec = S.csubR + (size_t)cid * 8;
         float4 sb[8];
 #pragma unroll
         for (int v = 0; v < 8; v++) sb[v] = srec[v];
-        const float4 rO = W.rayO[rr], rN = W.rayN[rr];
+        const float4 rO = rayO[rr], rN = rayN[rr];
         const bool rabn = (__float_as_int(rO.w) & 2) != 0;
         const F3 ro = f3(rO.x, rO.y, rO.z), rn = f3(rN.x, rN.y, rN.z);
         unsigned gmask = 0u;
@@ -858,26 +861,28 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
                 if (!__any(alive && spass)) continue;  // wave-uniform
             }
             // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
-            if (lane < ce) {
-                const int c = S.corder[cb + lane];
-                W.ccid[lane] = c;
-                W.csph[lane] = S.cclR[c];
+            for (int u = lane; u < ce; u += 64) {
+                const int c = S.corder[cb + u];
+                W.ccid[u] = c;
+                csph[u] = S.cclR[c];
             }
             lds_fence();
+            // (bit i of cmask: this lane's i-th cluster of the round, slot part + i * kPer; at most kPoolQ / kPer <= 32 of them)
             unsigned cmask = 0u;
-            for (int u = part; u < ce; u += kPer) {
-                const float4 b = W.csph[u];
+            for (int u = part, it = 0; u < ce; u += kPer, it++) {
+                const float4 b = csph[u];
                 if (alive && !aabn) ex_add(ex, EX_CONE);
-                if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << u;
+                if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
             }
             if (!alive) cmask = 0u;
             // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
             // cluster's sub-spheres (one cache line for the lot, where a list in ray order touches 64)
             int nB = 0;
             for (int u = 0; u < ce; u++) {
-                const bool bit = (cmask >> u) & 1u;
+                const bool bit = (u % kPer) == part && ((cmask >> (u / kPer)) & 1u);
                 const unsigned long long bal = __ballot(bit);
-                if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 5) | u);
+                if (bal == 0ull) continue;  // wave-uniform
+                if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 7) | u);
                 nB += __popcll(bal);
             }
             lds_fence();
@@ -1028,13 +1033,19 @@ __global__ __launch_bounds__(kBlock) void k_closest_f(SceneDev S, LevelDev L, co
 #define RTX_SPLIT_CLOSEST_LOG2 17
 #endif
 constexpr int kSplitClosest = 1 << RTX_SPLIT_CLOSEST_LOG2;
+// ... and 4 rays (16 lanes a ray in stage A, 128 clusters a round: two rounds where 16 rays take five) when even that leaves
+// most SIMDs without a wave: the deep generations of a rank's share hold a few thousand rays and cost a full per-wave chain each
+#ifndef RTX_SPLIT_CLOSEST4_LOG2
+#define RTX_SPLIT_CLOSEST4_LOG2 15
+#endif
+constexpr int kSplitClosest4 = 1 << RTX_SPLIT_CLOSEST4_LOG2;
 constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below this take the latency-oriented walk (k_closest_f<true>)
 
 #ifndef RTX_WAVES_LANES
 #define RTX_WAVES_LANES 5
 #endif
 template <bool EX = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_LANES))) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_LANES))) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, int split16, int split4)
 {
     __shared__ PoolLds pool[kBlock / 64];
     const int n = min(*nrays, L.cap);
@@ -1042,7 +1053,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVE
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
-    if (n <= kSplitClosest) {
+    if (n <= split4) {
+        if (blockIdx.x * 16 >= n) return;  // block-uniform
+        closest_pool<4>(S, L, n, blockIdx.x * 16 + w * 4, pool[w], ex);
+    } else if (n <= split16) {
         if (blockIdx.x * 64 >= n) return;  // block-uniform
         closest_pool<16>(S, L, n, blockIdx.x * 64 + w * 16, pool[w], ex);
     } else {

@@ -117,6 +117,7 @@ struct rtx_context {
     // and the chain need not queue behind an earlier generation's pass (measured: 5.88 -> 5.81 ms per 4K frame,
     // 1.36 -> 1.34 for a rank of 8; the last TWO generations there: slower, they delay the closest-hit chain).
     int main_from = 1 << 30;
+    int lanes16 = kSplitClosest, lanes4 = kSplitClosest4;  // k_closest_lanes: generations up to this many rays give a wave 16 / 4 rays instead of 64
     int split4 = kSplitRays, split8 = kSplitRays8;  // shadow generations up to this many rays: 4 / 8 workgroups per 256 rays
     std::vector<hipEvent_t> ev_fork, ev_pass;  // per generation: set-up done (main stream), shadow pass done (side stream)
     // k_closest_lanes' own cluster set (PackedScene::pc) for scenes of more than one segment; has_pc = false: S's own
@@ -229,6 +230,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     c->device = dev;
     c->params = *params;
     c->serial = (params->flags & RTX_F_SERIAL) != 0 || c->arena != nullptr;
+    if (const char* e = ab_knob("RTX_LANES16")) c->lanes16 = std::atoi(e);
+    if (const char* e = ab_knob("RTX_LANES4")) c->lanes4 = std::atoi(e);
     if (const char* e4 = ab_knob("RTX_SPLIT4")) c->split4 = std::atoi(e4);  // A/B aids for the split thresholds (same image)
     if (const char* e8 = ab_knob("RTX_SPLIT8")) c->split8 = std::atoi(e8);
     c->width = params->width;
@@ -814,6 +817,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static inline unsigned grid_for_isect(size_t cap);
+// k_closest_lanes: 64 rays a workgroup for generations of <= kSplitClosest rays, 16 for <= kSplitClosest4 (the kernel reads the live count)
+static inline unsigned grid_lanes_thin(size_t cap, int s16, int s4) { return std::max((unsigned)((std::min<size_t>(cap, (size_t)s16) + 63) / 64), (unsigned)((std::min<size_t>(cap, (size_t)s4) + 15) / 16)); }
 
 // Calibration pass (context_create_impl): closest hit + set-up of every generation, block of chunk_rows rows by block,
 // on the default stream; d_blk[block * levels + k] = rays of generation k in that block.  The levels hold worst-case
@@ -839,7 +844,7 @@ static int calibrate_counts(rtx_context* c, int* d_blk)
             const int spawn = (k < c->params.max_depth && k + 1 < levels) ? 1 : 0;
             if (!spawn) break;  // the last generation spawns nothing: its count is already known
             const unsigned g = grid_for(live_cap);
-            if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64))), dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
+            if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, grid_lanes_thin(live_cap, c->lanes16, c->lanes4))), dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
             else if (live_cap < kPrefetchRays) hipLaunchKernelGGL((k_closest_f<true, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             else hipLaunchKernelGGL((k_closest_f<false, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, rays + k + 1, spawn, c->d_overflow);
@@ -891,9 +896,9 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             if (count) hipLaunchKernelGGL(k_closest<true>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (exact_only) hipLaunchKernelGGL(k_closest<false>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, rays + k, c->d_tests);
             else if (k > 0) {
-                const dim3 gl(std::max(g, (unsigned)((std::min<size_t>(live_cap, (size_t)kSplitClosest) + 63) / 64)));
-                if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
-                else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k);
+                const dim3 gl(std::max(g, grid_lanes_thin(live_cap, c->lanes16, c->lanes4)));
+                if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
+                else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
             }
             else if (live_cap < kPrefetchRays) {
                 if (exec) hipLaunchKernelGGL((k_closest_f<true, true>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
@@ -1096,7 +1101,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM", "RTX_LANES16", "RTX_LANES4"})  // the A/B aids context creation reads
         if (const char* v = ab_knob(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }

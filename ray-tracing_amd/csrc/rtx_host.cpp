@@ -135,6 +135,9 @@ int rtx_scene_load(const char* path, rtx_scene** out)
     for (int slot = 0; slot < numobjects; slot++) {  // :863
         std::string kind;
         r.in >> kind;
+        // a stream that has failed stays failed: every later read is a no-op and every later slot matches no branch
+        // (SURVEY.md section 4), so the remaining slots -- up to 2^31 of them for a corrupt count -- change nothing
+        if (!r.in) break;
         if (kind == "sphere") {  // :866-885
             rtx_sphere s;
             std::memset(&s, 0, sizeof s);  // deterministic stand-in for the reference's indeterminate record (F5)

@@ -9,6 +9,7 @@
 #include "rtx_kernels_common.hip.h"
 #include "rtx_closest.hip.h"
 #include "rtx_shadow.hip.h"
+#include "rtx_cells.hip.h"
 #include "rtx_shade.hip.h"
 namespace rtx {
 #define SHADOW_ARGS SceneDev, ShadowQ, const int*, unsigned char*, int, int, int
@@ -18,6 +19,12 @@ template __global__ void k_shadow_pass<false, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, true, true>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, false, false>(SHADOW_ARGS);
+template __global__ void k_shadow_cells<false>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
+template __global__ void k_shadow_direct<false>(SceneDev, CellTab, LevelDev, const int*);
+template __global__ void k_cells_build<false>(SceneDev, int, const float*, int*, const int*, int2*);
+template __global__ void k_cells_build<true>(SceneDev, int, const float*, int*, const int*, int2*);
+template __global__ void k_aff_build<false>(SceneDev, int, const float*, int*, const int*, int*);
+template __global__ void k_aff_build<true>(SceneDev, int, const float*, int*, const int*, int*);
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 1
 template __global__ void k_shadow_pass<true, true>(SHADOW_ARGS);
@@ -25,16 +32,18 @@ template __global__ void k_shadow_pass<true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<true, true, true>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<true, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<true, false, false>(SHADOW_ARGS);
+template __global__ void k_shadow_cells<true>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
+template __global__ void k_shadow_direct<true>(SceneDev, CellTab, LevelDev, const int*);
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 2
 template __global__ void k_closest_f<false, false>(SceneDev, LevelDev, const int*);
 template __global__ void k_closest_f<true, false>(SceneDev, LevelDev, const int*);
-template __global__ void k_closest_lanes<false>(SceneDev, LevelDev, const int*);
+template __global__ void k_closest_lanes<false>(SceneDev, LevelDev, const int*, int, int);
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 3
 template __global__ void k_closest_f<false, true>(SceneDev, LevelDev, const int*);
 template __global__ void k_closest_f<true, true>(SceneDev, LevelDev, const int*);
-template __global__ void k_closest_lanes<true>(SceneDev, LevelDev, const int*);
+template __global__ void k_closest_lanes<true>(SceneDev, LevelDev, const int*, int, int);
 template __global__ void k_closest<false>(SceneDev, LevelDev, const int*, unsigned long long*);
 template __global__ void k_closest<true>(SceneDev, LevelDev, const int*, unsigned long long*);
 template __global__ void k_shadow<false>(SceneDev, LevelDev, const int*, unsigned long long*);
