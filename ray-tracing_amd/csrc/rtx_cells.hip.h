@@ -88,9 +88,70 @@ __device__ __forceinline__ Packet cell_packet(const CellCone& K, F3 apex)
 
 __device__ __forceinline__ float cell_rho(float D) { return 1.3e-4f + 3.8e-3f * D; }  // make_packet's, for one ray at distance D
 
+// ------------------------------------------------------------------------------------------------
+// TIGHT entries (the default).  The per-ray filter's pass region carries the FILTER's own slack -- a cone of 3.7e-3 rad
+// about the ray's origin for its binary32 evaluation -- and a table built on it lists what the filter can pass.  What a
+// list needs to hold is less: the primitives whose EXACT test can accept some ray of the cell.  rtx_bounds.cpp states
+// what acceptance implies about the ray's TRUE line (origin o, unit direction n, as real numbers):
+//   * triangle: the plane point P the test computes (raytracing.cpp:352) lies within eta = 8u (guard + |c| + R) of the
+//     line and inside the ball (c, R) of the filter record (R = Rs + eta: bound_sphere_triangle), and -- for triangles
+//     with an edge record, Q > 0 -- has every barycentric coordinate beta_i(P) >= -m_i as the kernel evaluates them
+//     (tri_edge_filter; m_0 = 2m), hence >= -1.5 m_i as real numbers (the evaluation error is < m / 4);
+//   * plain sphere: the discriminant the test computes (:205-212) differs from the real one by <= 12u (2 |X|^2 + r^2) in the
+//     filter's units, X = o - c, so dist(c, line)^2 <= r^2 (1 + 2^-14) + 64u |X|^2 -- the budget the filter itself grants
+//     (the 2^-18 direction scale) -- i.e. dist <= R + 2.0e-3 |X| with R the filter record's radius.
+// and every ray's line passes within delta = 2e-4 + 1e-6 dmax of its light (origin bias 1e-4 |normal|, rounding of the
+// normalised direction).  So, with the cell's cone (axis w, half-angle theta, NO widening) and rho the slack named:
+//   ball:      packet_test(cone, rho) on the filter record; triangles rho = delta; spheres rho = delta + 2.0e-3 X_j with
+//              X_j >= |o - c| for every origin within D_j of the light that the front test keeps: levels as before;
+//   triangle:  for each edge i the half-space G_i = { X : beta_i(X) >= -1.5 m_i } (beta_i is affine in space, constant
+//              along the triangle's normal); the points of a cell's line that can be P lie at axial coordinate sigma in
+//              [C.u - R - delta, C.u + R + delta] along u = -n, C = c - light; beta_i(light + e + sigma u) = k_i + a_i.(light
+//              - v) + a_i.e + sigma (a_i.u) is bounded above over the cell by interval arithmetic on sigma and a_i.u (both
+//              ranges from the cone); if that bound + 1.5 m_i + |a_i| eta is negative for some i, no ray of the cell is
+//              accepted.  NaN anywhere keeps the entry.
+// The front test (dfront) is unchanged.  The per-ray filter stays in the walk as a cheap, sound first test.
+// ------------------------------------------------------------------------------------------------
+constexpr float kExactSphereTan = 2.0e-3f;  // sqrt(64u / (1 - 64u)) = 1.953e-3, rounded up
+
+// true: NO ray of the cell can be accepted by triangle k's exact test (edge half-spaces; see above)
+__device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, const float4 q1, const float4 e0, const float4 e1,
+                                                const float4 mb, const float delta, const float eta)
+{
+    if (!(e1.w > 0.0f)) return false;  // no edge record (degenerate, huge, non-finite): the ball decides
+    const F3 u0 = f3(-K.w.x, -K.w.y, -K.w.z);
+    const float Cx = mb.x - Lp.x, Cy = mb.y - Lp.y, Cz = mb.z - Lp.z;
+    const float C2 = Cx * Cx + Cy * Cy + Cz * Cz, Cn = sqrtf(C2);
+    const float Cu = Cx * u0.x + Cy * u0.y + Cz * u0.z;
+    const float hC = sqrtf(fmaxf(0.0f, C2 - Cu * Cu)) + 1e-3f * Cn;
+    const float Rb = sqrtf(-mb.w) * 1.00001f;
+    const float slo = fminf(Cu * K.cLo, Cu) - hC * K.sT - Rb - delta - eta - 1e-4f * Cn;
+    const float shi = fmaxf(Cu * K.cLo, Cu) + hC * K.sT + Rb + delta + eta + 1e-4f * Cn;
+    const float smax = fmaxf(fabsf(slo), fabsf(shi));
+    const float Lvx = Lp.x - q1.x, Lvy = Lp.y - q1.y, Lvz = Lp.z - q1.z;  // light - v
+    const float Lvn = sqrtf(Lvx * Lvx + Lvy * Lvy + Lvz * Lvz);
+    const float m = e0.w;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float ax = i == 0 ? -(e0.x + e1.x) : (i == 1 ? e0.x : e1.x);
+        const float ay = i == 0 ? -(e0.y + e1.y) : (i == 1 ? e0.y : e1.y);
+        const float az = i == 0 ? -(e0.z + e1.z) : (i == 1 ? e0.z : e1.z);
+        const float ki = i == 0 ? 1.0f : 0.0f, mi = (i == 0 ? 3.0f : 1.5f) * m;
+        const float an = sqrtf(ax * ax + ay * ay + az * az);
+        const float g0 = ax * u0.x + ay * u0.y + az * u0.z;
+        const float gp = sqrtf(fmaxf(0.0f, an * an - g0 * g0)) + 1e-3f * an;
+        const float glo = fminf(g0 * K.cLo, g0) - gp * K.sT, ghi = fmaxf(g0 * K.cLo, g0) + gp * K.sT;
+        const float pmax = fmaxf(fmaxf(slo * glo, slo * ghi), fmaxf(shi * glo, shi * ghi));
+        const float fmax_ = ki + (ax * Lvx + ay * Lvy + az * Lvz) + an * (delta + eta) + pmax;
+        const float slack = 1e-4f * (1.0f + an * (Lvn + smax));
+        if (fmax_ + mi + slack < 0.0f) return true;
+    }
+    return false;
+}
+
 // One wave per (light, cell).  FILL = false: count the entries (cnt[cell]); FILL = true: collect, sort by dneed, store.
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int2* ent)
+__global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int2* ent, int tight)
 {
     __shared__ int2 buf[FILL ? kCellCap : 1];
     const int cell = blockIdx.x, lane = threadIdx.x;
@@ -100,35 +161,82 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
     Packet P = cell_packet(K, Lp);
     const float dm = dmax[li];
     P.rho = cell_rho(dm);
+    // tight entries: the cone as it is (no widening by the filter's tolerance), rho per entry
+    const float delta = 2e-4f + 1e-6f * dm;
+    Packet P0 = P;
+    {
+        const float c0 = fmaxf(0.0f, K.cLo - 4e-6f);
+        P0.cosT2 = c0 * c0;
+        P0.sinT = K.sT + 4e-6f;
+        P0.rho = delta + kExactSphereTan * (3.3f * dm) * 1.01f;  // >= every entry's own rho (rho_of below: D - s_lo + hX <= dmax + 2.1 |C|, |C| <= dmax)
+    }
+    const Packet& Pc = tight ? P0 : P;  // what the cluster spheres are tested with
     const int base = FILL ? off[cell] : 0;
     int n = 0;
     for (int cb = 0; cb < S.sncl; cb += 64) {
         const int c = cb + lane;
-        unsigned long long cm = __ballot(c < S.sncl && packet_test(P, S.scl[min(c, S.sncl - 1)]));
+        unsigned long long cm = __ballot(c < S.sncl && packet_test(Pc, S.scl[min(c, S.sncl - 1)]));
         while (cm) {
             const size_t mi = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
             cm &= cm - 1;
             const float4 mb = S.smem[mi];
             const int k = S.sidx[mi];
-            const bool keep = k >= 0 && packet_test(P, mb);
+            bool keep = false;
+            float dlev = -1.0f;
+            // C = c - light; s = axial coordinate of the centre on the origins' side, h = its distance from the axis
+            const float Cx = mb.x - Lp.x, Cy = mb.y - Lp.y, Cz = mb.z - Lp.z;
+            const float C2 = Cx * Cx + Cy * Cy + Cz * Cz, Cn = sqrtf(C2);
+            const float wC = K.w.x * Cx + K.w.y * Cy + K.w.z * Cz;
+            const float h = sqrtf(fmaxf(0.0f, C2 - wC * wC)) + 1e-3f * Cn;
+            const float R = sqrtf(-mb.w) * 1.00001f;
+            if (k >= 0 && !tight) {
+                keep = packet_test(P, mb);
+                if (FILL && keep) {
+                    // smallest level at which the entry passes (it passes at the last one)
+                    int lo = 0, hi = kCellLevels;
+                    Packet Pm = P;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        Pm.rho = cell_rho(dm * ((float)mid * (1.0f / (float)kCellLevels)));
+                        if (packet_test(Pm, mb)) hi = mid; else lo = mid + 1;
+                    }
+                    dlev = (lo == 0) ? -1.0f : dm * ((float)(lo - 1) * (1.0f / (float)kCellLevels)) * 0.999999f;
+                }
+            } else if (k >= 0 && k >= S.ns) {
+                // triangle: the ball (c, R) with the true line, then the edge half-spaces
+                Packet Pm = P0;
+                Pm.rho = delta;
+                keep = packet_test(Pm, mb);
+                if (keep && !S.mt) {  // (the Moeller-Trumbore mode has no edge records: the ball decides)
+                    const float eta = (S.guard + Cn + sqrtf(Lp.x * Lp.x + Lp.y * Lp.y + Lp.z * Lp.z) + R) * (8.0f / 16777216.0f) * 1.01f;
+                    const float4 q1 = S.tri_hot[(size_t)(k - S.ns) * 5 + 1];
+                    const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
+                    if (tri_cell_reject(K, Lp, q1, e0, e1, mb, delta, eta)) keep = false;
+                }
+            } else if (k >= 0) {
+                // plain sphere: rho grows with the distance |X| of the origin from the centre; for origins within D_j of the
+                // light that the front test keeps (D >= s - 1.2 R - ...), |X| <= max(D_j - s_lo, 1.2 R + ...) + h
+                const float s_lo = -wC - h * K.sT - fabsf(wC) * (1.0f - K.cLo) - 1e-3f * Cn;
+                const float xmin = 1.2f * R + 2e-3f * (Cn + dm) + 1e-2f;
+                const float hX = h + fabsf(wC) * K.sT;  // distance of the centre from a LINE of the cell (the axis turned by theta)
+                auto rho_of = [&](float D) { return delta + kExactSphereTan * ((fmaxf(D - s_lo, xmin) + hX) * 1.001f); };
+                Packet Pm = P0;
+                Pm.rho = rho_of(dm);
+                keep = packet_test(Pm, mb);
+                if (FILL && keep) {
+                    int lo = 0, hi = kCellLevels;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        Pm.rho = rho_of(dm * ((float)mid * (1.0f / (float)kCellLevels)));
+                        if (packet_test(Pm, mb)) hi = mid; else lo = mid + 1;
+                    }
+                    dlev = (lo == 0) ? -1.0f : dm * ((float)(lo - 1) * (1.0f / (float)kCellLevels)) * 0.999999f;
+                }
+            }
             const unsigned long long bal = __ballot(keep);
             if (FILL && keep) {
-                // smallest level at which the entry passes (it passes at the last one)
-                int lo = 0, hi = kCellLevels;
-                Packet Pm = P;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    Pm.rho = cell_rho(dm * ((float)mid * (1.0f / (float)kCellLevels)));
-                    if (packet_test(Pm, mb)) hi = mid; else lo = mid + 1;
-                }
-                const float dlev = (lo == 0) ? -1.0f : dm * ((float)(lo - 1) * (1.0f / (float)kCellLevels)) * 0.999999f;
-                // behind every origin within D of the light: n.C <= ub for every direction n of the cell, C = c - light
-                const float Cx = mb.x - Lp.x, Cy = mb.y - Lp.y, Cz = mb.z - Lp.z;
-                const float C2 = Cx * Cx + Cy * Cy + Cz * Cz, Cn = sqrtf(C2);
-                const float wC = K.w.x * Cx + K.w.y * Cy + K.w.z * Cz;
-                const float h = sqrtf(fmaxf(0.0f, C2 - wC * wC)) + 1e-3f * Cn;
+                // behind every origin within D of the light: n.C <= ub for every direction n of the cell
                 const float ub = (wC < 0.0f ? wC * K.cLo : wC) + h * K.sT;
-                const float R = sqrtf(-mb.w) * 1.00001f;
                 const float dfront = -ub - 1.005f * R - 1e-3f * (Cn + dm) - 1e-3f;
                 float dneed = fmaxf(dlev, dfront);
                 if (!(R < 1e18f) || dneed != dneed) dneed = -1.0f;  // records that always pass (R = inf): every ray takes them

@@ -439,6 +439,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 const size_t ncell0 = std::max((size_t)c->S.nl * G0 * G0, (size_t)1 << 24);
                 HIPCHK(hipMalloc((void**)&cnt, sizeof(int) * (ncell0 + 2 * ((ncell0 + 1023) / 1024) + 2) + sizeof(unsigned long long)));
             }
+            int cells_tight = 1;  // entries by what the exact tests can accept (rtx_cells.hip.h); 0: by what the per-ray filter can pass
+            if (const char* e = ab_knob("RTX_CELL_TIGHT")) cells_tight = std::atoi(e) ? 1 : 0;
             // count, 64-bit sum against the budget (a coarser map if it does not fit), scan, fill.  The plain table has one
             // list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
             auto build = [&](const bool affine, const int** off_out, const void** ent_out, int* G_out) -> int {
@@ -454,7 +456,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(cnt + (((size_t)ncell + 2 * (size_t)nb + 1) & ~(size_t)1));
                     HIPCHK(hipMemset(d_sum, 0, sizeof(unsigned long long)));
                     if (affine) hipLaunchKernelGGL(k_aff_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int*)nullptr);
-                    else hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr);
+                    else hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr, cells_tight);
                     hipLaunchKernelGGL(k_cells_sum, dim3(1024), dim3(kBlock), 0, 0, cnt, ncell, d_sum);
                     HIPCHK(hipGetLastError());
                     unsigned long long sum = 0;
@@ -472,7 +474,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     // the walks read a few entries past a list's end: plain { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
                     HIPCHK(hipMemset(ent + (size_t)total * esz, affine ? 0 : 0xff, esz * kCellPad));
                     if (affine) hipLaunchKernelGGL(k_aff_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int*>(ent));
-                    else hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int2*>(ent));
+                    else hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int2*>(ent), cells_tight);
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipDeviceSynchronize());
                     *off_out = off; *ent_out = ent; *G_out = G;
@@ -1101,7 +1103,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM", "RTX_LANES16", "RTX_LANES4"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM", "RTX_LANES16", "RTX_LANES4", "RTX_CELL_TIGHT"})  // the A/B aids context creation reads
         if (const char* v = ab_knob(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }

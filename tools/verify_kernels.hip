@@ -21,8 +21,8 @@ template __global__ void k_shadow_affine<false, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, false, false>(SHADOW_ARGS);
 template __global__ void k_shadow_cells<false>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
 template __global__ void k_shadow_direct<false>(SceneDev, CellTab, LevelDev, const int*);
-template __global__ void k_cells_build<false>(SceneDev, int, const float*, int*, const int*, int2*);
-template __global__ void k_cells_build<true>(SceneDev, int, const float*, int*, const int*, int2*);
+template __global__ void k_cells_build<false>(SceneDev, int, const float*, int*, const int*, int2*, int);
+template __global__ void k_cells_build<true>(SceneDev, int, const float*, int*, const int*, int2*, int);
 template __global__ void k_aff_build<false>(SceneDev, int, const float*, int*, const int*, int*);
 template __global__ void k_aff_build<true>(SceneDev, int, const float*, int*, const int*, int*);
 #endif
