@@ -104,47 +104,64 @@ __device__ __forceinline__ float cell_rho(float D) { return 1.3e-4f + 3.8e-3f * 
 // normalised direction).  So, with the cell's cone (axis w, half-angle theta, NO widening) and rho the slack named:
 //   ball:      packet_test(cone, rho) on the filter record; triangles rho = delta; spheres rho = delta + 2.0e-3 X_j with
 //              X_j >= |o - c| for every origin within D_j of the light that the front test keeps: levels as before;
-//   triangle:  for each edge i the half-space G_i = { X : beta_i(X) >= -1.5 m_i } (beta_i is affine in space, constant
-//              along the triangle's normal); the points of a cell's line that can be P lie at axial coordinate sigma in
-//              [C.u - R - delta, C.u + R + delta] along u = -n, C = c - light; beta_i(light + e + sigma u) = k_i + a_i.(light
-//              - v) + a_i.e + sigma (a_i.u) is bounded above over the cell by interval arithmetic on sigma and a_i.u (both
-//              ranges from the cone); if that bound + 1.5 m_i + |a_i| eta is negative for some i, no ray of the cell is
-//              accepted.  NaN anywhere keeps the entry.
+//   triangle:  the plane through the light and each edge line of the grown triangle (tri_cell_reject below): a cell whose
+//              cone lies wholly on the outer side of one of them holds no ray the test can accept.  NaN anywhere keeps the entry.
 // The front test (dfront) is unchanged.  The per-ray filter stays in the walk as a cheap, sound first test.
 // ------------------------------------------------------------------------------------------------
 constexpr float kExactSphereTan = 2.0e-3f;  // sqrt(64u / (1 - 64u)) = 1.953e-3, rounded up
 
-// true: NO ray of the cell can be accepted by triangle k's exact test (edge half-spaces; see above)
-__device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, const float4 q1, const float4 e0, const float4 e1,
+// true: NO ray of the cell can be accepted by triangle k's exact test.  q0 = { unit normal N, d }, q1 = { v, area } of the hot
+// record, e0 = { a1, m }, e1 = { a2, Q } of the edge record, mb the filter record (the ball).  Edge i of the grown triangle is the
+// line l_i = { X in the triangle's plane : beta_i(X) = -m_i' }, beta_i(X) = k_i + a_i.(X - v); the plane through the light and l_i
+// (normal n_i, turned towards a_i) cuts the triangle's plane into beta_i >= -m_i' and the rest, so a line through the light with
+// direction u meets the triangle's plane on the inside of edge i iff sign(sigma) n_i.u >= 0, sigma the axial coordinate of the
+// meeting point (its sign is known when the ball does not straddle the light).  A line that misses the light by |e| <= delta
+// moves that by |e| / |sigma|.  The accepted point P is not the meeting point X* itself: it lies within eta of the line and
+// within ~eta of the plane, hence within 40 eta of X* unless the ray grazes the plane (|N.u| < 0.05: no decision then), which
+// m_i' = 1.5 m_i + 40 eta |a_i| + 1e-4 absorbs.
+__device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, const float4 q0, const float4 q1, const float4 e0, const float4 e1,
                                                 const float4 mb, const float delta, const float eta)
 {
     if (!(e1.w > 0.0f)) return false;  // no edge record (degenerate, huge, non-finite): the ball decides
     const F3 u0 = f3(-K.w.x, -K.w.y, -K.w.z);
+    const float Nu = q0.x * u0.x + q0.y * u0.y + q0.z * u0.z;
+    if (!(fabsf(Nu) - K.sT > 0.05f)) return false;  // some ray of the cell may graze the plane
     const float Cx = mb.x - Lp.x, Cy = mb.y - Lp.y, Cz = mb.z - Lp.z;
     const float C2 = Cx * Cx + Cy * Cy + Cz * Cz, Cn = sqrtf(C2);
     const float Cu = Cx * u0.x + Cy * u0.y + Cz * u0.z;
     const float hC = sqrtf(fmaxf(0.0f, C2 - Cu * Cu)) + 1e-3f * Cn;
     const float Rb = sqrtf(-mb.w) * 1.00001f;
+    // axial range (along u = -n, from the light) of the points of a cell's line that lie within eta of the ball
     const float slo = fminf(Cu * K.cLo, Cu) - hC * K.sT - Rb - delta - eta - 1e-4f * Cn;
     const float shi = fmaxf(Cu * K.cLo, Cu) + hC * K.sT + Rb + delta + eta + 1e-4f * Cn;
-    const float smax = fmaxf(fabsf(slo), fabsf(shi));
-    const float Lvx = Lp.x - q1.x, Lvy = Lp.y - q1.y, Lvz = Lp.z - q1.z;  // light - v
-    const float Lvn = sqrtf(Lvx * Lvx + Lvy * Lvy + Lvz * Lvz);
+    if (!(slo > 0.0f) && !(shi < 0.0f)) return false;  // the ball straddles the light
+    const float off = (delta + eta) / (slo > 0.0f ? slo : -shi) + 6e-5f;  // what missing the light by delta + eta can turn a line by, + the rounding of n_i (<= 2.4e-5 under the guards below)
     const float m = e0.w;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float ax = i == 0 ? -(e0.x + e1.x) : (i == 1 ? e0.x : e1.x);
         const float ay = i == 0 ? -(e0.y + e1.y) : (i == 1 ? e0.y : e1.y);
         const float az = i == 0 ? -(e0.z + e1.z) : (i == 1 ? e0.z : e1.z);
-        const float ki = i == 0 ? 1.0f : 0.0f, mi = (i == 0 ? 3.0f : 1.5f) * m;
-        const float an = sqrtf(ax * ax + ay * ay + az * az);
-        const float g0 = ax * u0.x + ay * u0.y + az * u0.z;
-        const float gp = sqrtf(fmaxf(0.0f, an * an - g0 * g0)) + 1e-3f * an;
+        const float ki = i == 0 ? 1.0f : 0.0f;
+        const float an2 = ax * ax + ay * ay + az * az, an = sqrtf(an2);
+        const float mi = (i == 0 ? 3.0f : 1.5f) * m + 40.0f * eta * an + 1e-4f;
+        // a point of l_i and its direction (in the plane, along which beta_i is constant)
+        const float lam = (-mi - ki) / an2;
+        const float wx = q1.x + lam * ax - Lp.x, wy = q1.y + lam * ay - Lp.y, wz = q1.z + lam * az - Lp.z;  // p_i - light
+        const float tx = q0.y * az - q0.z * ay, ty = q0.z * ax - q0.x * az, tz = q0.x * ay - q0.y * ax;      // N x a_i
+        float nx = ty * wz - tz * wy, ny = tz * wx - tx * wz, nz = tx * wy - ty * wx;                        // t_i x (p_i - light)
+        const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+        const float tn = sqrtf(tx * tx + ty * ty + tz * tz), wn = sqrtf(wx * wx + wy * wy + wz * wz);
+        if (!(nn > 1e-2f * tn * wn)) continue;  // the light lies (nearly) on l_i itself: no decision from this edge
+        const float na = nx * ax + ny * ay + nz * az;
+        if (!(fabsf(na) > 1e-2f * nn * an)) continue;  // the light lies (nearly) in the triangle's plane: which side is inside is not safe to say
+        const float sgn = na >= 0.0f ? 1.0f / nn : -1.0f / nn;
+        nx *= sgn; ny *= sgn; nz *= sgn;
+        const float g0 = nx * u0.x + ny * u0.y + nz * u0.z;
+        const float gp = sqrtf(fmaxf(0.0f, 1.0f - g0 * g0)) + 1e-5f;
         const float glo = fminf(g0 * K.cLo, g0) - gp * K.sT, ghi = fmaxf(g0 * K.cLo, g0) + gp * K.sT;
-        const float pmax = fmaxf(fmaxf(slo * glo, slo * ghi), fmaxf(shi * glo, shi * ghi));
-        const float fmax_ = ki + (ax * Lvx + ay * Lvy + az * Lvz) + an * (delta + eta) + pmax;
-        const float slack = 1e-4f * (1.0f + an * (Lvn + smax));
-        if (fmax_ + mi + slack < 0.0f) return true;
+        if (slo > 0.0f) { if (ghi < -off) return true; }   // every line meets the plane outside edge i
+        else { if (glo > off) return true; }
     }
     return false;
 }
@@ -209,9 +226,9 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
                 keep = packet_test(Pm, mb);
                 if (keep && !S.mt) {  // (the Moeller-Trumbore mode has no edge records: the ball decides)
                     const float eta = (S.guard + Cn + sqrtf(Lp.x * Lp.x + Lp.y * Lp.y + Lp.z * Lp.z) + R) * (8.0f / 16777216.0f) * 1.01f;
-                    const float4 q1 = S.tri_hot[(size_t)(k - S.ns) * 5 + 1];
+                    const float4 q0 = S.tri_hot[(size_t)(k - S.ns) * 5], q1 = S.tri_hot[(size_t)(k - S.ns) * 5 + 1];
                     const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
-                    if (tri_cell_reject(K, Lp, q1, e0, e1, mb, delta, eta)) keep = false;
+                    if (tri_cell_reject(K, Lp, q0, q1, e0, e1, mb, delta, eta)) keep = false;
                 }
             } else if (k >= 0) {
                 // plain sphere: rho grows with the distance |X| of the origin from the centre; for origins within D_j of the
