@@ -308,6 +308,15 @@ int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capa
 int  rtx_cluster_records(const rtx_scene* scene, int32_t which, float* cluster4, float* sub4, float* member4,
                          int32_t* index, int32_t capacity);
 
+/* The direction map of the shadow stage (rtx_shadow.hip.h: light_cell; rtx_cells.hip.h: cell_cone), the kernels' own functions
+ * compiled for the host.  rtx_light_cell: the cell (Morton index, 0 .. G*G-1) of the G x G octahedral map a direction falls
+ * into (NaN components land in cell 0), G <= 4096.  rtx_cell_cone: out7 = { axis x y z, sin(half-angle) rounded up,
+ * cos(half-angle) rounded down, cell column, cell row }: every direction rtx_light_cell maps to `cell` lies within that
+ * half-angle of the axis, which is what the (light, cell) tables are built on.  Exported so the CPU suite can check both at
+ * every map size in use.  No counterpart in the reference. */
+int  rtx_light_cell(const float* dir3, int32_t G);
+int  rtx_cell_cone(int32_t cell, int32_t G, float* out7);
+
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),
  * records zero-filled before parsing.  Polygons keep parseinput's rules: normal from the

@@ -44,7 +44,7 @@ constexpr int kCellLevels = 32;
 constexpr int kCellCap = 2048;   // entries one build wave sorts in LDS; longer lists are stored unsorted with dneed = -1
 constexpr int kCellPad = 4;      // readable entries behind the last list (the walk loads four at a time)
 
-__device__ __forceinline__ F3 oct_decode(float qx, float qy)
+__host__ __device__ __forceinline__ F3 oct_decode(float qx, float qy)
 {
     const float z = 1.0f - fabsf(qx) - fabsf(qy);
     if (z >= 0.0f) return f3(qx, qy, z);
@@ -54,7 +54,7 @@ __device__ __forceinline__ F3 oct_decode(float qx, float qy)
 // axis, sin(half-angle) rounded up, cos(half-angle) rounded down of the cone around cell m of the G x G map
 struct CellCone { F3 w; float sT, cLo; };
 
-__device__ __forceinline__ CellCone cell_cone(unsigned m, int G)
+__host__ __device__ __forceinline__ CellCone cell_cone(unsigned m, int G)
 {
     const float gx = (float)demorton12(m), gy = (float)demorton12(m >> 1), s = 2.0f / (float)G;
     const F3 vc = oct_decode((gx + 0.5f) * s - 1.0f, (gy + 0.5f) * s - 1.0f);

@@ -29,6 +29,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -221,6 +222,15 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out);
 
 static int context_create_impl(const rtx_scene* scene, const rtx_params* params, rtx_context* c)
 {
+    const bool verbose = ab_knob("RTX_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "rtx: create %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RTX_E_NO_DEVICE;
     int dev = params->device;
@@ -253,8 +263,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (need[y]) { c->row2ti[y] = (int)c->trace_rows.size(); c->trace_rows.push_back(y); }
     const int ntrace = (int)c->trace_rows.size();
 
+    phase("rows");
     PackedScene P;
     pack_scene(*scene, W, H, P, params->flags);
+    phase("pack_scene (host)");
     c->singular = P.singular;
     c->fanout = P.max_fanout;
     c->levels = (P.max_fanout == 0) ? 1 : params->max_depth + 1;
@@ -375,6 +387,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.box_lo = {lo[0], lo[1], lo[2]};
             c->S.box_inv = {inv[0], inv[1], inv[2]};
         }
+        phase("scene upload");
         // The (light, direction cell) tables cover origins up to the far corner of the scene box (rays from further away,
         // possible only through the reference's odd hit points on affine spheres, are traced against every sphere).
         std::vector<float> dt(c->S.nl);
@@ -430,13 +443,17 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->upload(&d_dc, dc))) return rc;
             int G0 = 512;
             if (const char* e = ab_knob("RTX_CELL_G")) G0 = std::max(8, std::min(4096, std::atoi(e)));
-            while ((size_t)c->S.nl * G0 * G0 > ((size_t)1 << 24) && G0 > 8) G0 /= 2;
+            // a finer map for dense scenes, as the sort grid of the packet form takes (C5, 100,000 triangles: 78.5 / 56.6 / 47.0 ms
+            // per frame with 256 / 512 / 1024 cells a side; C4, 10,000 primitives: 2.88 / 2.76 / 2.82)
+            if (c->S.nsb >= 32768 && !ab_knob("RTX_CELL_G")) G0 = 1024;
+            constexpr size_t kMaxLists = (size_t)1 << 26;
+            while ((size_t)c->S.nl * G0 * G0 > kMaxLists && G0 > 8) G0 /= 2;
             // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
             int* cnt = nullptr;
             {
-                const size_t ncell0 = std::max((size_t)c->S.nl * G0 * G0, (size_t)1 << 24);
+                const size_t ncell0 = std::max((size_t)c->S.nl * G0 * G0, c->S.naff > 0 ? std::min((size_t)1 << 24, (size_t)c->S.nl * G0 * G0 * kAffSlabs) : (size_t)0);
                 HIPCHK(hipMalloc((void**)&cnt, sizeof(int) * (ncell0 + 2 * ((ncell0 + 1023) / 1024) + 2) + sizeof(unsigned long long)));
             }
             int cells_tight = 1;  // entries by what the exact tests can accept (rtx_cells.hip.h); 0: by what the per-ray filter can pass
@@ -447,7 +464,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 const int mult = affine ? kAffSlabs : 1;
                 const size_t esz = affine ? sizeof(int) : sizeof(int2);
                 for (int G = G0; G >= 8; G /= 2) {
-                    if ((size_t)c->S.nl * G * G * mult > ((size_t)1 << 24)) continue;
+                    // (the affine lists gain nothing from cells finer than 256 a side -- what they list is set by the slabs of origin
+                    // distance, 13.8 M filter tests per C4 frame either way -- and 33 M lists take 29 ms to build against 6)
+                    if ((size_t)c->S.nl * G * G * mult > (affine ? ((size_t)1 << 24) : kMaxLists)) continue;
                     const int nwave = c->S.nl * G * G;       // one build wave per (light, cell)
                     const int ncell = nwave * mult;          // lists
                     const int nb = (ncell + 1023) / 1024;
@@ -478,6 +497,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipDeviceSynchronize());
                     *off_out = off; *ent_out = ent; *G_out = G;
+                    if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: %s table G = %d, %d lists, %d entries\n", affine ? "affine" : "plain", G, ncell, total);
                     return RTX_OK;
                 }
                 return RTX_OK;  // no map is coarse enough: no table
@@ -487,11 +507,13 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 const void* e = nullptr;
                 rc = build(false, &c->cells.off, &e, &c->cells.G);
                 c->cells.ent = static_cast<const int2*>(e);
+                phase("plain table");
                 // (without the plain table the packet kernels trace everything, with their own affine stage)
                 if (!rc && c->cells.off && c->S.naff > 0) {
                     e = nullptr;
                     rc = build(true, &c->cells.aoff, &e, &c->cells.aG);
                     c->cells.aent = static_cast<const int*>(e);
+                    phase("affine table");
                 }
             }
             (void)hipFree(cnt);
@@ -521,6 +543,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             }
         }
         c->packet_allocs.assign(c->allocs.begin() + bitmask_mark, c->allocs.end());
+        phase("affine bit masks");
         float* ix = nullptr; float* iy = nullptr;
         if ((rc = c->upload(&ix, P.imagex))) return rc;
         if ((rc = c->upload(&iy, P.imagey))) return rc;
@@ -719,6 +742,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         caps = caps_for(m);
         c->calibrated = true;
     }
+    phase("calibration");
     c->chunk_rows = (int)rows;
     // Two-level member selection in the shadow pass (rtx_shadow.hip.h, shadow_select) for frames that fill the chip:
     // chunks of >= 2^22 primary rays (a whole 4K frame or half of one; any 8K share).  Thinner frames -- a rank of 4 or 8
@@ -754,6 +778,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * 2))) return rc;
     }
+    phase("queue allocation");
     if (c->arena) return RTX_OK;  // arena mode creates no streams and no events
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -794,6 +819,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             }
             tables = ms[1] <= ms[0];
             c->rendered = false;
+            phase("timing the two forms");
         } else if (force >= 0) {
             tables = can_tables && force == 1;
         }
@@ -813,6 +839,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->dfree_group(c->table_allocs);
             c->cells = CellTab{};
         }
+        phase("freeing the other form");
     }
     return RTX_OK;
 }
@@ -1608,6 +1635,23 @@ int rtx_render_rgb8_noalloc(const rtx_scene* scene, const rtx_params* params, ui
     rtx_context_destroy(c);  // waits for the stream; nothing on the device to free
     return rc;
     RTX_CATCH
+}
+
+// The direction map of the shadow stage, as the kernels compute it (the same functions, compiled for the host): the cell of
+// a direction, and the cone the (light, cell) tables are built with.  Pure host functions, no device needed.
+int rtx_light_cell(const float* dir3, int32_t G)
+{
+    if (!dir3 || G < 1 || G > 4096) return RTX_E_INVALID_ARG;
+    return light_cell(f3(dir3[0], dir3[1], dir3[2]), G);
+}
+
+int rtx_cell_cone(int32_t cell, int32_t G, float* out7)
+{
+    if (!out7 || G < 1 || G > 4096 || cell < 0 || (int64_t)cell >= (int64_t)G * G) return RTX_E_INVALID_ARG;
+    const CellCone K = cell_cone((unsigned)cell, G);
+    out7[0] = K.w.x; out7[1] = K.w.y; out7[2] = K.w.z; out7[3] = K.sT; out7[4] = K.cLo;
+    out7[5] = (float)demorton12((unsigned)cell); out7[6] = (float)demorton12((unsigned)cell >> 1);
+    return RTX_OK;
 }
 
 void rtx_release_cached_context(void)

@@ -17,8 +17,8 @@ namespace rtx {
 
 struct F3 { float x, y, z; };
 
-__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 v; v.x = x; v.y = y; v.z = z; return v; }
-__device__ __forceinline__ F3 f3(const rtx_vec3& a) { return f3(a.x, a.y, a.z); }
+__host__ __device__ __forceinline__ F3 f3(float x, float y, float z) { F3 v; v.x = x; v.y = y; v.z = z; return v; }
+__host__ __device__ __forceinline__ F3 f3(const rtx_vec3& a) { return f3(a.x, a.y, a.z); }
 
 // raytracing.cpp:127-130
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }

@@ -43,7 +43,7 @@ struct ShadowQ { float4 *a, *b; };
 // holds 64 rays inside a cone of a degree or so with its apex AT the light, the packet test keeps a
 // few dozen of the 10,000 primitives, and the 64 rays tend to be blocked by the same primitive.
 // (12 bits per axis: direction maps of up to 4096 x 4096 cells; rtx_device.hip uses 256 or 512 for the sort, 256 for the affine table)
-__device__ __forceinline__ unsigned morton12(unsigned x)
+__host__ __device__ __forceinline__ unsigned morton12(unsigned x)
 {
     x &= 0xfffu;
     x = (x | (x << 8)) & 0x00ff00ffu;
@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned morton12(unsigned x)
     return x;
 }
 
-__device__ __forceinline__ int light_cell(F3 v, int G)
+__host__ __device__ __forceinline__ int light_cell(F3 v, int G)
 {
     float s = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
     float inv = 1.0f / fmaxf(s, 1e-30f);
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool affine_strip_pass(const StripPacket& K, float4 m
 //     hit point, the ray from a point 1e-4 off it (raytracing.cpp:568).
 // Built once per context; the pass ORs the masks of the cells its rays fall into and runs the strip test of its
 // own, tighter packet on those spheres only.
-__device__ __forceinline__ unsigned demorton12(unsigned x)
+__host__ __device__ __forceinline__ unsigned demorton12(unsigned x)
 {
     x &= 0x55555555u;
     x = (x | (x >> 1)) & 0x33333333u;

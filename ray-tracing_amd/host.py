@@ -123,6 +123,8 @@ assert C.sizeof(Plane) == 40 and C.sizeof(Triangle) == 88 and C.sizeof(Light) ==
 SYMBOLS = {
     "rtx_abi_version": (C.c_uint32, []),
     "rtx_release_cached_context": (None, []),
+    "rtx_light_cell": (C.c_int, [C.POINTER(C.c_float), C.c_int32]),
+    "rtx_cell_cone": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "rtx_strerror": (C.c_char_p, [C.c_int]),
     "rtx_device_count": (C.c_int, []),
     "rtx_last_hip_error": (C.c_char_p, []),
