@@ -234,8 +234,9 @@ int rtx_render_rgb8(const rtx_scene* scene, const rtx_params* params, int ngpus,
 /* Frees the context the one-shot entry points keep (no-op if none).  No counterpart in the reference. */
 void rtx_release_cached_context(void);
 
-/* The same call (ngpus = 1) for callers that cannot allocate device memory -- code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference.  Scene records, ray queues, the
+/* The same call (ngpus = 1) for callers that cannot allocate device memory -- tight serving loops, harnesses that forbid
+ * hipMalloc.  (NOT for code under HIP graph capture: the call uploads the scene with synchronous copies, reads the frame
+ * back and waits for the default stream.)  NO counterpart in the reference.  Scene records, ray queues, the
  * float image and the 8-bit rows all live in one file-scope `static __device__` array of RTX_NOALLOC_SCRATCH_MIB MiB
  * that every GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree, creates no
  * stream and no event, and traces the frame in as many row chunks as that block needs (everything on the default

@@ -376,6 +376,7 @@ struct CellsLds {
 struct CellTab {
     const int* off; const int2* ent; const float* dmax; int G;
     const int* aoff; const int* aent; int aG;   // affine lists per (light, cell, slab)
+    int nofilter;                                // A/B: entries go to the exact stages without the per-ray filter
 };
 
 // One lane = one shadow ray (o, ld) towards light li.  Returns true for the lanes whose ray is blocked by a plain
@@ -415,7 +416,8 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
     int nS = 0, nT = 0, nA = 0, nX = 0;
 
     // S / T / A: the pooled exact stages of shadow_plain_pool (rtx_shadow.hip.h), same tests on the same records
-    auto run_S = [&](const int cnt) {
+    auto run_S = [&](const int want) {
+        const int cnt = min(want, nS);  // (never more than the list holds: a drain cannot index below it)
         const int b0 = nS - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listS[b0 + (has ? lane : 0)];
@@ -431,7 +433,8 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
         lds_fence();
     };
     // X: exact affine-sphere tests (raytracing.cpp:571-582): direction through the inverse matrix, origin as it is
-    auto run_X = [&](const int cnt) {
+    auto run_X = [&](const int want) {
+        const int cnt = min(want, nX);  // (never more than the list holds: a drain cannot index below it)
         const int b0 = nX - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listX[b0 + (has ? lane : 0)];
@@ -447,7 +450,8 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
         nX = b0;
         lds_fence();
     };
-    auto run_A = [&](const int cnt) {
+    auto run_A = [&](const int want) {
+        const int cnt = min(want, nA);  // (never more than the list holds: a drain cannot index below it)
         const int b0 = nA - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listA[b0 + (has ? lane : 0)];
@@ -463,7 +467,8 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
         nA = b0;
         lds_fence();
     };
-    auto run_T = [&](const int cnt) {
+    auto run_T = [&](const int want) {
+        const int cnt = min(want, nT);  // (never more than the list holds: a drain cannot index below it)
         const int b0 = nT - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listT[b0 + (has ? lane : 0)];
@@ -510,9 +515,13 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
         const bool t1 = t0 && pos + 1 < end && D >= __int_as_float(e1.y);
         const bool t2 = t1 && pos + 2 < end && D >= __int_as_float(e2.y);
         const bool t3 = t2 && pos + 3 < end && D >= __int_as_float(e3.y);
-        const float4 b0 = S.bounds[t0 ? e0.x : 0], b1 = S.bounds[t1 ? e1.x : 0], b2 = S.bounds[t2 ? e2.x : 0], b3 = S.bounds[t3 ? e3.x : 0];
-        if (EX) ex_add(ex, EX_FILT, (unsigned)t0 + (unsigned)t1 + (unsigned)t2 + (unsigned)t3);
-        const bool pass[4] = { t0 && filt_front(o, fd, b0), t1 && filt_front(o, fd, b1), t2 && filt_front(o, fd, b2), t3 && filt_front(o, fd, b3) };
+        bool pass[4] = { t0, t1, t2, t3 };
+        if (!T.nofilter) {  // kernel-uniform
+            const float4 b0 = S.bounds[t0 ? e0.x : 0], b1 = S.bounds[t1 ? e1.x : 0], b2 = S.bounds[t2 ? e2.x : 0], b3 = S.bounds[t3 ? e3.x : 0];
+            if (EX) ex_add(ex, EX_FILT, (unsigned)t0 + (unsigned)t1 + (unsigned)t2 + (unsigned)t3);
+            pass[0] = t0 && filt_front(o, fd, b0); pass[1] = t1 && filt_front(o, fd, b1);
+            pass[2] = t2 && filt_front(o, fd, b2); pass[3] = t3 && filt_front(o, fd, b3);
+        }
         const int kk[4] = { e0.x, e1.x, e2.x, e3.x };
         pos = t3 ? pos + 4 : end;  // sorted by dneed: the first entry beyond this ray's distance ends its list
 #pragma unroll

@@ -809,11 +809,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         }
     };
     // B: one (ray, cluster) per lane: its 8 sub-cluster spheres against the ray's cone
-    auto run_B = [&](int base, int cnt) {
-        const bool has = lane < cnt;
-        const unsigned e = W.listB[base + (has ? lane : 0)];
-        const int rr = (int)(e >> 7);
-        const int cid = W.ccid[e & 127u];
+    auto do_B = [&](const bool has, const int rr, const int cid) {
         const float4* srec = S.csubR + (size_t)cid * 8;
         float4 sb[8];
 #pragma unroll
@@ -839,58 +835,143 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
             if (nC >= 64) run_C(64);
         }
     };
+    auto run_B = [&](int base, int cnt) {
+        const bool has = lane < cnt;
+        const unsigned e = W.listB[base + (has ? lane : 0)];
+        do_B(has, (int)(e >> 7), W.ccid[e & 127u]);
+    };
 
     const int ncl = S.cseg[S.cnseg];
     static_assert(kPoolQ % kSuperRun == 0, "a round of stage A is a whole number of ClusterSet::supR runs");
     const int nsup0 = (S.cnfirst + kSuperRun - 1) / kSuperRun;
+    if constexpr (R == 64) {
+      // ---- 64 rays a wave: the RUN level is pooled too (round 3).  A ray passes ~6 of C4's 20 runs of 8 clusters; testing every
+      //      cluster of every round for every ray (lanes in lockstep: a round cost its 8 cone tests whenever ANY ray passed its run)
+      //      was 157 of the 225 cone tests per ray.  Now a lane tests its ray against the run's sphere only, the passing (ray, run)
+      //      pairs collect in LDS in run order, and whenever 64 wait each lane takes one pair and tests its 8 cluster spheres. ----
+      unsigned* const listR = reinterpret_cast<unsigned*>(W.listB);          // [128]  ray << 20 | run
+      unsigned* const listB32 = reinterpret_cast<unsigned*>(W.listB) + 128;  // [128]  ray << 26 | cluster
+      static_assert(kPoolB * sizeof(unsigned short) >= 256 * sizeof(unsigned), "the two lists fit listB's space");
+      constexpr unsigned kPrimMaskB = (1u << kPoolPrimBits) - 1u;
+      int nR = 0, nB = 0;
+      int cendv = 0, cbegv = 0, sbase = 0;
+      auto run_B32 = [&](const int want) {
+          const int cnt = min(want, nB), base = nB - cnt;
+          const bool has = lane < cnt;
+          const unsigned e = listB32[base + (has ? lane : 0)];
+          nB = base;
+          do_B(has, (int)(e >> kPoolPrimBits), (int)(e & kPrimMaskB));
+      };
+      auto run_R = [&](const int want) {
+          const int cnt = min(want, nR), base = nR - cnt;
+          const bool has = lane < cnt;
+          const unsigned e = listR[base + (has ? lane : 0)];
+          nR = base;
+          const int rr = (int)(e >> 20);
+          const int p0 = cbegv + ((int)(e & 0xfffffu) - sbase) * kSuperRun;  // the run's first cluster in traversal order
+          const int pc = min(kSuperRun, cendv - p0);
+          const float4 rO = rayO[rr], rN = rayN[rr];
+          const bool rabn = (__float_as_int(rO.w) & 2) != 0;
+          const F3 ro = f3(rO.x, rO.y, rO.z), rn = f3(rN.x, rN.y, rN.z);
+          int cid[kSuperRun];
+          float4 sb[kSuperRun];
+#pragma unroll
+          for (int v = 0; v < kSuperRun; v++) cid[v] = S.corder[min(p0 + v, cendv - 1)];
+#pragma unroll
+          for (int v = 0; v < kSuperRun; v++) sb[v] = S.cclR[cid[v]];
+          unsigned cm = 0u;
+#pragma unroll
+          for (int v = 0; v < kSuperRun; v++)
+              if (v < pc && (rabn || !((front ? cone_slack_front(ro, rn, sb[v]) : cone_slack(ro, rn, sb[v])) < 0.0f))) cm |= 1u << v;
+          if (has && !rabn) ex_add(ex, EX_CONE, (unsigned)pc);
+          if (!has) cm = 0u;
+          // (rolled: every copy of this loop's body holds a whole B -> C -> D nest, 8 x 8 exact-test bodies)
+#pragma nounroll
+          for (int v = 0; v < kSuperRun; v++) {
+              const bool pass = (cm >> v) & 1u;
+              const unsigned long long bal = __ballot(pass);
+              if (bal == 0ull) continue;  // wave-uniform
+              int cv = cid[0];
+#pragma unroll
+              for (int u = 1; u < kSuperRun; u++) cv = (u == v) ? cid[u] : cv;  // (a select chain: no dynamically indexed register array)
+              if (pass) listB32[nB + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)cv;
+              nB += __popcll(bal);
+              lds_fence();
+              if (nB >= 64) run_B32(64);
+          }
+      };
+      for (int phase = 0; phase < 2; phase++) {
+          cbegv = phase ? S.cnfirst : 0; cendv = phase ? ncl : S.cnfirst;
+          sbase = phase ? nsup0 : 0;
+          front = phase == 1;
+          const int nruns = (cendv - cbegv + kSuperRun - 1) / kSuperRun;
+          for (int sr = 0; sr < nruns; sr++) {
+              const float4 sup = S.csupR[sbase + sr];
+              if (alive && !aabn) ex_add(ex, EX_CONE);
+              const bool pass = alive && (aabn || !(cone_slack(ao, an, sup) < 0.0f));
+              const unsigned long long bal = __ballot(pass);
+              if (bal == 0ull) continue;  // wave-uniform: no ray of the wave passes the run
+              if (pass) listR[nR + lanes_below(bal)] = ((unsigned)lane << 20) | (unsigned)(sbase + sr);
+              nR += __popcll(bal);
+              lds_fence();
+              if (nR >= 64) run_R(64);
+          }
+          // phase 0: every affine-sphere hit is known before the first plain sphere is tested
+          while (nR > 0) run_R(nR);
+          while (nB > 0) run_B32(nB);
+          if (nC > 0) run_C(nC);
+          if (nD > 0) run_D(nD);
+      }
+    } else {
     for (int phase = 0; phase < 2; phase++) {
-        const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
-        front = phase == 1;
-        for (int cb = cbeg; cb < cend; cb += kPoolQ) {
-            const int ce = min(kPoolQ, cend - cb);
-            // ---- the spheres around the round's runs of 8 clusters first: a wave none of whose rays can pass one
-            //      skips the round ----
-            {
-                const int s0 = (phase ? nsup0 : 0) + (cb - cbeg) / kSuperRun, sn = (ce + kSuperRun - 1) / kSuperRun;
-                bool spass = aabn;
-                for (int v = 0; v < sn; v++) {
-                    const float4 sup = S.csupR[s0 + v];
-                    if (alive && !aabn) ex_add(ex, EX_CONE);
-                    spass = spass || !(cone_slack(ao, an, sup) < 0.0f);
-                }
-                if (!__any(alive && spass)) continue;  // wave-uniform
-            }
-            // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
-            for (int u = lane; u < ce; u += 64) {
-                const int c = S.corder[cb + u];
-                W.ccid[u] = c;
-                csph[u] = S.cclR[c];
-            }
-            lds_fence();
-            // (bit i of cmask: this lane's i-th cluster of the round, slot part + i * kPer; at most kPoolQ / kPer <= 32 of them)
-            unsigned cmask = 0u;
-            for (int u = part, it = 0; u < ce; u += kPer, it++) {
-                const float4 b = csph[u];
-                if (alive && !aabn) ex_add(ex, EX_CONE);
-                if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
-            }
-            if (!alive) cmask = 0u;
-            // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
-            // cluster's sub-spheres (one cache line for the lot, where a list in ray order touches 64)
-            int nB = 0;
-            for (int u = 0; u < ce; u++) {
-                const bool bit = (u % kPer) == part && ((cmask >> (u / kPer)) & 1u);
-                const unsigned long long bal = __ballot(bit);
-                if (bal == 0ull) continue;  // wave-uniform
-                if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 7) | u);
-                nB += __popcll(bal);
-            }
-            lds_fence();
-            for (int p0 = 0; p0 < nB; p0 += 64) run_B(p0, min(64, nB - p0));
-        }
-        // phase 0: every affine-sphere hit is known before the first plain sphere is tested
-        if (nC > 0) run_C(nC);
-        if (nD > 0) run_D(nD);
+          const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
+          front = phase == 1;
+          for (int cb = cbeg; cb < cend; cb += kPoolQ) {
+              const int ce = min(kPoolQ, cend - cb);
+              // ---- the spheres around the round's runs of 8 clusters first: a wave none of whose rays can pass one
+              //      skips the round ----
+              {
+                  const int s0 = (phase ? nsup0 : 0) + (cb - cbeg) / kSuperRun, sn = (ce + kSuperRun - 1) / kSuperRun;
+                  bool spass = aabn;
+                  for (int v = 0; v < sn; v++) {
+                      const float4 sup = S.csupR[s0 + v];
+                      if (alive && !aabn) ex_add(ex, EX_CONE);
+                      spass = spass || !(cone_slack(ao, an, sup) < 0.0f);
+                  }
+                  if (!__any(alive && spass)) continue;  // wave-uniform
+              }
+              // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
+              for (int u = lane; u < ce; u += 64) {
+                  const int c = S.corder[cb + u];
+                  W.ccid[u] = c;
+                  csph[u] = S.cclR[c];
+              }
+              lds_fence();
+              // (bit i of cmask: this lane's i-th cluster of the round, slot part + i * kPer; at most kPoolQ / kPer <= 32 of them)
+              unsigned cmask = 0u;
+              for (int u = part, it = 0; u < ce; u += kPer, it++) {
+                  const float4 b = csph[u];
+                  if (alive && !aabn) ex_add(ex, EX_CONE);
+                  if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
+              }
+              if (!alive) cmask = 0u;
+              // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
+              // cluster's sub-spheres (one cache line for the lot, where a list in ray order touches 64)
+              int nB = 0;
+              for (int u = 0; u < ce; u++) {
+                  const bool bit = (u % kPer) == part && ((cmask >> (u / kPer)) & 1u);
+                  const unsigned long long bal = __ballot(bit);
+                  if (bal == 0ull) continue;  // wave-uniform
+                  if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 7) | u);
+                  nB += __popcll(bal);
+              }
+              lds_fence();
+              for (int p0 = 0; p0 < nB; p0 += 64) run_B(p0, min(64, nB - p0));
+          }
+          // phase 0: every affine-sphere hit is known before the first plain sphere is tested
+          if (nC > 0) run_C(nC);
+          if (nD > 0) run_D(nD);
+      }
     }
     bool aliveList = false;
 #pragma unroll

@@ -519,6 +519,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             (void)hipFree(cnt);
             if (rc) return rc;
             c->cells.dmax = d_dc;
+            // tight entries go straight to the exact stages: the per-ray filter in front of them rejected one pair in five and cost
+            // a gather and eleven instructions per pair (C4 2.85 -> 2.75 ms, C5 47.1 -> 43.9 ms); filter-conservative entries keep it
+            c->cells.nofilter = cells_tight;
+            if (const char* e = ab_knob("RTX_CELL_NOFILTER")) c->cells.nofilter = std::atoi(e) ? 1 : 0;
             c->table_allocs.assign(c->allocs.begin() + tab_mark, c->allocs.end());
             c->use_cells = c->cells.off != nullptr;
             c->shadow_direct = c->cells.off && (c->S.naff == 0 || c->cells.aoff);
@@ -1130,7 +1134,7 @@ static void hash_call(const rtx_scene* sc, const rtx_params* p, int dev, uint64_
     h.bytes(n, sizeof n);
     const int64_t q[9] = { p->width, p->height, p->max_depth, p->nranks, p->rank, p->band_rows, (int64_t)p->flags, (int64_t)p->workspace_bytes, 0 };
     h.bytes(q, sizeof q);
-    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM", "RTX_LANES16", "RTX_LANES4", "RTX_CELL_TIGHT"})  // the A/B aids context creation reads
+    for (const char* name : {"RTX_SHADOW_POOL_FROM", "RTX_SPLIT4", "RTX_SPLIT8", "RTX_TWO_LEVEL", "RTX_BIN_G", "RTX_CELLS", "RTX_CELL_G", "RTX_SHADOW_DIRECT", "RTX_SHADOW_FORM", "RTX_LANES16", "RTX_LANES4", "RTX_CELL_TIGHT", "RTX_CELL_NOFILTER"})  // the A/B aids context creation reads
         if (const char* v = ab_knob(name)) { h.bytes(name, std::strlen(name)); h.bytes(v, std::strlen(v)); }
     key[0] = h.a; key[1] = h.b;
 }

@@ -444,7 +444,8 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
 
     // S: exact sphere tests (raytracing.cpp:202-228, :577-582) of the last cnt (<= 64) entries.  The shadow cluster set
     // holds no transformed sphere (rtx_pack.cpp: those go through the affine strip test), so the ray is (o, normalize(ld)).
-    auto run_S = [&](const int cnt) {
+    auto run_S = [&](const int want) {
+        const int cnt = min(want, nS);  // (never more than the list holds: a drain at a lower threshold cannot index below the list)
         const int base = nS - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listS[base + (has ? lane : 0)];
@@ -460,7 +461,8 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
         lds_fence();
     };
     // A: the three areas (raytracing.cpp:352-365) for the entries the edge filter could not decide
-    auto run_A = [&](const int cnt) {
+    auto run_A = [&](const int want) {
+        const int cnt = min(want, nA);  // (never more than the list holds: a drain at a lower threshold cannot index below the list)
         const int base = nA - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listA[base + (has ? lane : 0)];
@@ -477,7 +479,8 @@ __device__ __forceinline__ int shadow_plain_pool(const SceneDev& S, const Packet
         lds_fence();
     };
     // T: the exact triangle test up to the edge filter (raytracing.cpp:338-350 + rtx_bounds.cpp, tri_edge_filter)
-    auto run_T = [&](const int cnt) {
+    auto run_T = [&](const int want) {
+        const int cnt = min(want, nT);  // (never more than the list holds: a drain at a lower threshold cannot index below the list)
         const int base = nT - cnt;
         const bool has = lane < cnt;
         const unsigned e = W.listT[base + (has ? lane : 0)];

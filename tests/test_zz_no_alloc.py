@@ -14,8 +14,16 @@ pytestmark = pytest.mark.gpu
 
 
 def _same(rt, sc, p):
+    import torch
     want, sw = rt.render_rgb8(sc, p)
+    rt.host.release_cached_context()          # (the one-shot call's kept context: free it, so what is compared below is this call alone)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     got, sg = rt.render_rgb8_noalloc(sc, p)
+    free1 = torch.cuda.mem_get_info()[0]
+    # "allocates nothing": the device's free memory is what it was (a frame's buffers would be tens of MiB; the slack is for
+    # the runtime's own kernel-argument pools)
+    assert free0 - free1 < (4 << 20), "rtx_render_rgb8_noalloc took %.1f MiB of device memory" % ((free0 - free1) / 2**20)
     assert got.shape == want.shape
     assert np.array_equal(got, want), "%d bytes differ" % int((got != want).sum())
     assert (sg.rays_primary, sg.rays_secondary, sg.rays_shadow, sg.hits) == (sw.rays_primary, sw.rays_secondary, sw.rays_shadow, sw.hits)
