@@ -69,6 +69,10 @@ static inline const char* ab_knob(const char*) { return nullptr; }
 
 #include "rtx_kernels_common.hip.h"
 #include "rtx_closest.hip.h"
+namespace rtx {  // compiled in rtx_lanes.hip (the Makefile builds the two files side by side)
+extern template __global__ void k_closest_lanes<false>(SceneDev, LevelDev, const int*, int, int);
+extern template __global__ void k_closest_lanes<true>(SceneDev, LevelDev, const int*, int, int);
+}
 #include "rtx_shadow.hip.h"
 #include "rtx_cells.hip.h"
 #include "rtx_shade.hip.h"

@@ -232,6 +232,7 @@ __device__ __forceinline__ void ex_flush(Exec* ex, unsigned long long* dst)
 // K1 ray generation (raytracing.cpp:753-759); origin is one constant (:735-737) but is stored
 // per ray so that every level has the same layout.
 // ------------------------------------------------------------------------------------------------
+#ifndef RTX_LANES_TU  // (a plain kernel has one definition: rtx_device.hip's; rtx_lanes.hip holds k_closest_lanes only)
 __global__ __launch_bounds__(kBlock) void k_raygen(LevelDev L, CamDev C, const int* trace_rows, int ti0,
                                                    int nrows, int width, int* nrays)
 {
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(LevelDev L, CamDev C, const i
     L.ox[i] = C.orig.x; L.oy[i] = C.orig.y; L.oz[i] = C.orig.z;
     L.dx[i] = d.x; L.dy[i] = d.y; L.dz[i] = d.z;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // K2 closest hit (raytracing.cpp:382-419).  One ray per lane; the primitive index is
