@@ -347,6 +347,33 @@ __device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
     return behind ? -1.0f : __builtin_fmaf(rhs * 1.00001f, rhs, -(h2 * cosE2));
 }
 
+// cone_slack_front with what lies wholly BEYOND a distance taken out as well (round 3): lr = 1.015625 L + 1e-5 guard for a ray
+// whose state cannot be changed by a hit at t > L (closest_pool).  b = { c, R } encloses bounding spheres of plain spheres,
+// triangles and polygons only.  A hit the exact tests accept has its point in the primitive's bounding sphere (rtx_bounds.cpp:
+// the triangle's sphere holds P = o + t d AS COMPUTED; a plain sphere's root lies on it up to the rounding below), so
+// n.(P - o) >= n.(c - o) - |n| R = as - R for every sphere b around it, and
+//   triangle, polygon: t (n.d) = n.(P - o) - n.eps, |eps| <= 8u (guard + t), n.d in [0.998, 1.002] (ray_abnormal admits
+//     |d - n| <= 1e-5 per component, |n|^2 = 1 +- 8u from normalized()): t >= (as - R - 1e-6 guard) / 1.0021;
+//   plain sphere (sphere_test: t >= t0 = (-b - sqrt(disc)) / 2, -b / 2 = n.(c - o) +- 4u |X|, disc / 4 <= r^2 (1 + 12u) + 32u |X|^2
+//     as computed, and an accepted hit has |X| <= 1.00001 (as + r)): t >= as (1 - 1.5e-3) - r (1 + 1.5e-3) - 1e-6 guard,
+//     and for an enclosing sphere (as_m <= as + R, r_m <= R): t >= as (1 - 1.5e-3) - R (1 + 3e-3) - 1e-6 guard.
+// The test as * (1 - 1/128) - R * (1 + 1/64) > 1.015625 L + 1e-5 guard therefore puts every such t strictly above L, with the
+// rounding of as itself (4u |c - o| <= 1e-6 guard) a tenth of the absolute term.  R = +inf and NaN compare false: no cull.
+__device__ __forceinline__ float cone_slack_cull(F3 o, F3 n, float4 b, float lr)
+{
+    const float cosE2 = 0.9999783f;
+    const float sinE = 3.705e-3f;
+    const float Cx = b.x - o.x, Cy = b.y - o.y, Cz = b.z - o.z;
+    const float C2 = __builtin_fmaf(Cx, Cx, __builtin_fmaf(Cy, Cy, Cz * Cz));
+    const float as = __builtin_fmaf(n.x, Cx, __builtin_fmaf(n.y, Cy, n.z * Cz));
+    const float a = fabsf(as);
+    const float h2 = __builtin_fmaf(-a, a, C2 * (1.0f - 4e-6f));
+    const float rhs = __builtin_fmaf(a, sinE, b.w * 1.00001f + 1e-20f);
+    const bool behind = as < 0.0f && as * as > __builtin_fmaf(1.01f * b.w, b.w, 1e-6f * C2);
+    const bool far = __builtin_fmaf(as, 0.9921875f, -1.015625f * b.w) > lr;
+    return (behind || far) ? -1.0f : __builtin_fmaf(rhs * 1.00001f, rhs, -(h2 * cosE2));
+}
+
 // packet_test for a sphere given as { c, R } (cluster and sub-cluster spheres of the per-ray hierarchy, clR / subR)
 __device__ __forceinline__ bool packet_test_R(const Packet& P, float4 b)
 {
@@ -729,7 +756,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     if (inq) ex_add(ex, EX_RAYS);
     if (lane < R) {
         rayO[lane] = make_float4(o.x, o.y, o.z, __int_as_float((live ? 1 : 0) | (abn ? 2 : 0)));
-        rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+        rayN[lane] = make_float4(nd.x, nd.y, nd.z, __builtin_inff());  // .w: the ray's far limit (cone_slack_cull), phase 1
         rayD[lane] = make_float4(d.x, d.y, d.z, 0.0f);
     }
     W.slot[lane] = -1;
@@ -744,6 +771,16 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     int nC = 0, nD = 0, tested = 0;
     bool front = false;  // phase 1 (no affine spheres): primitives behind the ray's origin are skipped
 
+    // What a hit beyond L cannot change (phase 1: plain spheres, triangles, polygons): the nearest hit needs t < nearest or
+    // t == nearest with a lower index, an affine entry of the staircase is killed by a plain sphere at t <= its own; so
+    // L = max(nearest, the live entries' t).  L only falls as hits arrive, a stale value in LDS is a larger one.
+    const float cull_abs = 1e-5f * S.guard;
+    auto far_limit = [&]() {
+        float lim = h.nearest;
+#pragma unroll
+        for (int e = 0; e < kAffList; e++) lim = (h.ak[e] >= 0) ? fmaxf(lim, h.at[e]) : lim;
+        return __builtin_fmaf(lim, 1.015625f, cull_abs);
+    };
     // E: hand the hits of a D step to the owners of their rays, one hit per ray per round
     auto deliver = [&](bool pending, int rr, int k, float t, int kind) {
         while (__any(pending)) {
@@ -756,6 +793,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
                 const int e = W.inK[lane];
                 lex_update(h, e & ((1 << 28) - 1), W.inT[lane], e >> 28);
                 W.slot[lane] = -1;
+                if (front) rayN[lane].w = far_limit();
             }
             lds_fence();
         }
@@ -799,13 +837,17 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
             if (kk[v] >= 0 && (!use || (front ? filt_front(fo, fd, mb[v]) : !(filt(fo, fd, mb[v]) < 0.0f)))) pmask |= 1u << v;
         }
         if (!has) pmask = 0u;
-        // pushes in MEMBER order: neighbouring lanes (rays of one group) that pass the same member sit together in D
-#pragma unroll
-        for (int v = 0; v < kGroup; v++) {
-            const bool pass = (pmask >> v) & 1u;
+        // every lane pushes its lowest passing member, as many times as the busiest lane has members (0.35 of 8 pass)
+        for (;;) {
+            const bool pass = pmask != 0u;
             const unsigned long long bal = __ballot(pass);
-            if (bal == 0ull) continue;  // wave-uniform
-            if (pass) W.listD[nD + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)kk[v];
+            if (bal == 0ull) break;  // wave-uniform
+            const int v = __builtin_ctz(pmask | 0x100u);
+            int kv = kk[0];
+#pragma unroll
+            for (int u = 1; u < kGroup; u++) kv = (u == v) ? kk[u] : kv;  // (a select chain: no dynamically indexed register array)
+            if (pass) W.listD[nD + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)kv;
+            pmask &= pmask - 1u;
             nD += __popcll(bal);
             lds_fence();
             if (nD >= 64) run_D(64);
@@ -823,16 +865,19 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
         unsigned gmask = 0u;
 #pragma unroll
         for (int v = 0; v < 8; v++)
-            if (rabn || !((front ? cone_slack_front(ro, rn, sb[v]) : cone_slack(ro, rn, sb[v])) < 0.0f)) gmask |= 1u << v;
+            if (rabn || !((front ? cone_slack_cull(ro, rn, sb[v], rN.w) : cone_slack(ro, rn, sb[v])) < 0.0f)) gmask |= 1u << v;
         if (has && !rabn) ex_add(ex, EX_CONE, 8u);
         if (!has) gmask = 0u;
-        // pushes in GROUP order (the lanes are already in cluster order): the 64 entries of a C step then name
-        // few distinct groups, whose members neighbouring lanes read together; a C step as soon as 64 entries wait
-        for (int v = 0; v < 8; v++) {
-            const bool pass = (gmask >> v) & 1u;
+        // every lane pushes its lowest passing group, as many times as the busiest lane has groups (1.2 of 8 pass on the
+        // benchmark frame: 3 or 4 rounds where a loop over the 8 groups took 8); a C step as soon as 64 entries wait.
+        // The lanes are in cluster order, so the 64 entries of a C step still name few clusters' members.
+        for (;;) {
+            const bool pass = gmask != 0u;
             const unsigned long long bal = __ballot(pass);
-            if (bal == 0ull) continue;  // wave-uniform
-            if (pass) W.listC[nC + lanes_below(bal)] = ((unsigned)cid << 9) | ((unsigned)rr << 3) | (unsigned)v;
+            if (bal == 0ull) break;  // wave-uniform
+            const unsigned v = (unsigned)__builtin_ctz(gmask | 0x100u);
+            if (pass) W.listC[nC + lanes_below(bal)] = ((unsigned)cid << 9) | ((unsigned)rr << 3) | v;
+            gmask &= gmask - 1u;
             nC += __popcll(bal);
             lds_fence();
             if (nC >= 64) run_C(64);
@@ -885,19 +930,21 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
           unsigned cm = 0u;
 #pragma unroll
           for (int v = 0; v < kSuperRun; v++)
-              if (v < pc && (rabn || !((front ? cone_slack_front(ro, rn, sb[v]) : cone_slack(ro, rn, sb[v])) < 0.0f))) cm |= 1u << v;
+              if (v < pc && (rabn || !((front ? cone_slack_cull(ro, rn, sb[v], rN.w) : cone_slack(ro, rn, sb[v])) < 0.0f))) cm |= 1u << v;
           if (has && !rabn) ex_add(ex, EX_CONE, (unsigned)pc);
           if (!has) cm = 0u;
-          // (rolled: every copy of this loop's body holds a whole B -> C -> D nest, 8 x 8 exact-test bodies)
-#pragma nounroll
-          for (int v = 0; v < kSuperRun; v++) {
-              const bool pass = (cm >> v) & 1u;
+          // every lane pushes its lowest passing cluster, as many times as the busiest lane has clusters
+          // (a loop, not unrolled: every copy of its body holds a whole B -> C -> D nest)
+          for (;;) {
+              const bool pass = cm != 0u;
               const unsigned long long bal = __ballot(pass);
-              if (bal == 0ull) continue;  // wave-uniform
+              if (bal == 0ull) break;  // wave-uniform
+              const int v = __builtin_ctz(cm | 0x100u);
               int cv = cid[0];
 #pragma unroll
               for (int u = 1; u < kSuperRun; u++) cv = (u == v) ? cid[u] : cv;  // (a select chain: no dynamically indexed register array)
               if (pass) listB32[nB + lanes_below(bal)] = ((unsigned)rr << kPoolPrimBits) | (unsigned)cv;
+              cm &= cm - 1u;
               nB += __popcll(bal);
               lds_fence();
               if (nB >= 64) run_B32(64);
@@ -911,7 +958,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
           for (int sr = 0; sr < nruns; sr++) {
               const float4 sup = S.csupR[sbase + sr];
               if (alive && !aabn) ex_add(ex, EX_CONE);
-              const bool pass = alive && (aabn || !(cone_slack(ao, an, sup) < 0.0f));
+              const bool pass = alive && (aabn || !((front ? cone_slack_cull(ao, an, sup, far_limit()) : cone_slack(ao, an, sup)) < 0.0f));
               const unsigned long long bal = __ballot(pass);
               if (bal == 0ull) continue;  // wave-uniform: no ray of the wave passes the run
               if (pass) listR[nR + lanes_below(bal)] = ((unsigned)lane << 20) | (unsigned)(sbase + sr);
@@ -924,8 +971,11 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
           while (nB > 0) run_B32(nB);
           if (nC > 0) run_C(nC);
           if (nD > 0) run_D(nD);
+          if (lane < R) rayN[lane].w = far_limit();  // phase 1 culls beyond what phase 0 found
+          lds_fence();
       }
     } else {
+    float alr = __builtin_inff();
     for (int phase = 0; phase < 2; phase++) {
           const int cbeg = phase ? S.cnfirst : 0, cend = phase ? ncl : S.cnfirst;
           front = phase == 1;
@@ -936,10 +986,11 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
               {
                   const int s0 = (phase ? nsup0 : 0) + (cb - cbeg) / kSuperRun, sn = (ce + kSuperRun - 1) / kSuperRun;
                   bool spass = aabn;
+                  alr = rayN[myray].w;  // this round's far limit of the lane's ray (its owner lowers it as hits arrive)
                   for (int v = 0; v < sn; v++) {
                       const float4 sup = S.csupR[s0 + v];
                       if (alive && !aabn) ex_add(ex, EX_CONE);
-                      spass = spass || !(cone_slack(ao, an, sup) < 0.0f);
+                      spass = spass || !((front ? cone_slack_cull(ao, an, sup, alr) : cone_slack(ao, an, sup)) < 0.0f);
                   }
                   if (!__any(alive && spass)) continue;  // wave-uniform
               }
@@ -955,7 +1006,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
               for (int u = part, it = 0; u < ce; u += kPer, it++) {
                   const float4 b = csph[u];
                   if (alive && !aabn) ex_add(ex, EX_CONE);
-                  if (aabn || !((front ? cone_slack_front(ao, an, b) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
+                  if (aabn || !((front ? cone_slack_cull(ao, an, b, alr) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
               }
               if (!alive) cmask = 0u;
               // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
@@ -974,6 +1025,8 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
           // phase 0: every affine-sphere hit is known before the first plain sphere is tested
           if (nC > 0) run_C(nC);
           if (nD > 0) run_D(nD);
+          if (lane < R) rayN[lane].w = far_limit();  // phase 1 culls beyond what phase 0 found
+          lds_fence();
       }
     }
     bool aliveList = false;
