@@ -153,6 +153,8 @@ struct rtx_context {
                                             // the packet kernels (k_shadow_pass) trace the plain primitives
     bool shadow_direct = false;             // the table kernels read the hit records themselves: no shadow queue, no sort (k_shadow_direct)
     bool use_cells = false;                 // this context's shadow stage goes through the tables (false: the packet kernels, k_shadow_pass)
+    bool form_early = false;                // the tables were chosen before the queues were allocated (short lists or RTX_F_SHADOW_TABLES):
+                                            // the packet form's bit masks and shadow queues are never built
     std::vector<void*> table_allocs, packet_allocs;  // what only one of the two forms needs (the other's is freed once the form is chosen)
     int pool_from = 1;                      // first generation whose shadow pass takes the pooled stages (shadow_plain_pool): generation 0's
                                             // coherent rays keep the one-survivor-at-a-time walk; RTX_SHADOW_POOL_FROM=k: A/B aid
@@ -168,10 +170,36 @@ struct rtx_context {
     bool calibrated = false;                // level capacities come from the calibration pass (fan-out 2 scenes)
     bool serial = false;                    // RTX_F_SERIAL / arena mode: everything on the caller's stream, no side streams, no fork/join events
 
+    // Slab: between slab_begin and slab_end every dalloc that fits is carved out of ONE hipMalloc (256-byte aligned).  The ray
+    // records of the generations are ~100 arrays: as separate blocks they cost 3 ms to allocate and 18 ms to free
+    // (tools/ubench/malloc_cost.hip: 4 GiB in 96 blocks), as one block 1.5 + 0.6 ms -- the calibration pass allocates and frees
+    // its worst-case set inside context creation.  A slab is freed as a whole (it is one entry of `allocs`).
+    char* slab = nullptr;
+    size_t slab_cap = 0, slab_off = 0;
+    int slab_begin(size_t bytes)
+    {
+        if (arena) return RTX_OK;
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, std::max<size_t>(bytes, 256)));
+        allocs.push_back(q);
+        slab = (char*)q; slab_cap = std::max<size_t>(bytes, 256); slab_off = 0;
+        return RTX_OK;
+    }
+    void slab_end() { slab = nullptr; slab_cap = slab_off = 0; }
+    static size_t round256(size_t b) { return (std::max<size_t>(b, 1) + 255) & ~(size_t)255; }
+
     template <typename T> int dalloc(T** p, size_t n)
     {
         void* q = nullptr;
         if (n == 0) n = 1;
+        if (slab) {
+            const size_t bytes = round256(n * sizeof(T));
+            if (bytes <= slab_cap - slab_off) {
+                *p = (T*)(slab + slab_off);
+                slab_off += bytes;
+                return RTX_OK;
+            }
+        }
         if (arena) {
             const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
             if (bytes > arena_cap - arena_off) return RTX_E_TOO_LARGE;
@@ -464,6 +492,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if (const char* e = ab_knob("RTX_CELL_TIGHT")) cells_tight = std::atoi(e) ? 1 : 0;
             // count, 64-bit sum against the budget (a coarser map if it does not fit), scan, fill.  The plain table has one
             // list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
+            uint64_t tab_entries[2] = {0, 0}, tab_lists[2] = {0, 0};
             auto build = [&](const bool affine, const int** off_out, const void** ent_out, int* G_out) -> int {
                 const int mult = affine ? kAffSlabs : 1;
                 const size_t esz = affine ? sizeof(int) : sizeof(int2);
@@ -501,6 +530,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipDeviceSynchronize());
                     *off_out = off; *ent_out = ent; *G_out = G;
+                    tab_entries[affine ? 1 : 0] = (uint64_t)total; tab_lists[affine ? 1 : 0] = (uint64_t)ncell;
                     if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: %s table G = %d, %d lists, %d entries\n", affine ? "affine" : "plain", G, ncell, total);
                     return RTX_OK;
                 }
@@ -531,10 +561,24 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->use_cells = c->cells.off != nullptr;
             c->shadow_direct = c->cells.off && (c->S.naff == 0 || c->cells.aoff);
             if (const char* e = ab_knob("RTX_SHADOW_DIRECT")) c->shadow_direct = c->shadow_direct && std::atoi(e) != 0;
+            // Which form the shadow stage takes is measured at the end of creation (both forms render this context's frame) --
+            // unless the answer is plain: forced by a flag, or lists so short that the walk cannot lose.  What a shadow ray pays in
+            // the table form is its list (4 entries a step); the packet form lost on every frame measured whose lists average
+            // below 30 entries (C4: 2.3 plain and 3.4 affine, 2.5 against 4.2 ms; C5: 8 per list, 40 against 85 ms), so lists
+            // of <= 16 on average skip the measurement, the packet form's bit masks and its queues: 18 ms of a 74 ms creation.
+            {
+                int force = -1;
+                if (params->flags & RTX_F_SHADOW_PACKETS) force = 0;
+                if (params->flags & RTX_F_SHADOW_TABLES) force = 1;
+                if (const char* e = ab_knob("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;
+                const bool shortl = tab_entries[0] <= 16 * tab_lists[0] && tab_entries[1] <= 16 * tab_lists[1];
+                c->form_early = c->use_cells && c->shadow_direct && (force == 1 || (force < 0 && shortl));
+                if (ab_knob("RTX_FORM_MEASURE") && force < 0) c->form_early = false;
+            }
         }
         c->S.aff_cells = nullptr; c->S.aff_dt = nullptr; c->S.aff_words = 0; c->S.aff_G = 0;
         const size_t bitmask_mark = c->allocs.size();
-        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0) {
+        if (c->S.naff > 0 && c->S.naff <= 4096 && c->S.nl > 0 && !c->form_early) {
             // (light, direction cell) -> affine spheres bit masks for the packet form's k_shadow_affine (k_affine_cells)
             const int words = (c->S.naff + 63) / 64;
             int G = 256;
@@ -616,7 +660,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     // Device bytes of the ray queues for these capacities, allocation by allocation as alloc_levels / alloc_shadow do
     // (arena mode rounds every allocation up to 256 bytes); nchunks only sizes the per-chunk counters.
     auto plan_levels = [&](const Caps& cp, bool with_lit) -> double {
-        auto al = [&](double b) { return c->arena ? std::ceil(std::max(b, 1.0) / 256.0) * 256.0 : b; };
+        auto al = [&](double b) { return std::ceil(std::max(b, 1.0) / 256.0) * 256.0; };  // (arena and slab both round up)
         double tot = 0;
         for (int k = 0; k < levels; k++) {
             const double cap = (double)cp.cap[k];
@@ -625,7 +669,8 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         return tot;
     };
     auto plan_shadow = [&](const Caps& cp, double nch) -> double {
-        auto al = [&](double b) { return c->arena ? std::ceil(std::max(b, 1.0) / 256.0) * 256.0 : b; };
+        if (c->form_early) return std::ceil(std::max(nch * levels * 4.0 * 2.0, 1.0) / 256.0) * 256.0;  // tables: no shadow queues
+        auto al = [&](double b) { return std::ceil(std::max(b, 1.0) / 256.0) * 256.0; };
         size_t mx = 0;
         for (size_t v : cp.cap) mx = std::max(mx, v);
         const double qcap = (double)mx * (double)nl1 + (double)c->qpad;
@@ -637,8 +682,13 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         for (size_t v : cp.cap) mx = std::max(mx, v);
         return (double)mx * (double)nl1 + (double)c->qpad > (double)(((int64_t)1 << 30));
     };
-    auto alloc_levels = [&](const Caps& cp, bool with_lit) -> int {
+    auto alloc_levels = [&](const Caps& cp, bool with_lit, size_t extra = 0) -> int {
         c->L.assign(levels, LevelDev{});
+        {   // one block for the lot (plan_levels counts what the loop below carves, cap >= 1 each)
+            Caps c1 = cp;
+            for (size_t& v : c1.cap) v = std::max<size_t>(v, 1);
+            if ((rc = c->slab_begin((size_t)plan_levels(c1, with_lit) + rtx_context::round256(extra)))) return rc;
+        }
         for (int k = 0; k < levels; k++) {
             LevelDev& L = c->L[k];
             const size_t cap = std::max<size_t>(cp.cap[k], 1);
@@ -709,8 +759,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         {
             const size_t mark_allocs = c->allocs.size(), mark_arena = c->arena_off;
             int* d_blk = nullptr;
-            if ((rc = alloc_levels(worst_caps(r_cal), false))) return rc;
+            if ((rc = alloc_levels(worst_caps(r_cal), false, blk.size() * sizeof(int)))) return rc;
             if ((rc = c->dalloc(&d_blk, blk.size()))) return rc;
+            c->slab_end();
             c->chunk_rows = (int)r_cal;
             if ((rc = calibrate_counts(c, d_blk))) return rc;
             HIPCHK(hipMemcpy(blk.data(), d_blk, blk.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -764,16 +815,26 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((int64_t)rows * W <= ((int64_t)3 << 20)) c->pool_from = 0;
     if (const char* pf = ab_knob("RTX_SHADOW_POOL_FROM")) c->pool_from = std::atoi(pf);  // A/B aid; same image either way
     if ((rc = alloc_levels(caps, true))) return rc;
-    {   // shadow-ray queues: the largest generation's hits x lights
+    c->slab_end();
+    c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
+    if (c->form_early) {
+        if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * 2))) return rc;
+    } else {   // shadow-ray queues: the largest generation's hits x lights
         size_t mx = 0;
         for (int k = 0; k < levels; k++) mx = std::max(mx, (size_t)c->L[k].cap);
         size_t qcap = mx * nl1 + c->qpad;
         if (qcap > ((size_t)1 << 31) - 1) return RTX_E_TOO_LARGE;
         const size_t maxbins = (size_t)c->nbins;
+        const size_t qmark = c->allocs.size();
+        {
+            const size_t ng = (maxbins + 1023) / 1024;
+            auto r256 = rtx_context::round256;
+            const size_t per = 2 * r256(qcap * sizeof(*c->side[0].q.a)) + 2 * r256(maxbins * 4) + r256(qcap * 4) + 2 * r256(ng * 4);
+            if ((rc = c->slab_begin(per * (size_t)nlanes))) return rc;
+        }
         for (int i = 0; i <= nside; i++) {
             if (i == nside && c->main_from >= levels) break;
             rtx_context::ShadowLane& sl = c->side[i == nside ? (int)rtx_context::kSide : i];
-            const size_t qmark = c->allocs.size();
             if ((rc = c->dalloc(&sl.q.a, qcap))) return rc;
             if ((rc = c->dalloc(&sl.q.b, qcap))) return rc;
             if ((rc = c->dalloc(&sl.hist, maxbins))) return rc;
@@ -781,8 +842,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->dalloc(&sl.rank, qcap))) return rc;
             if ((rc = c->dalloc(&sl.bsum, (maxbins + 1023) / 1024))) return rc;
             if ((rc = c->dalloc(&sl.braw, (maxbins + 1023) / 1024))) return rc;
-            c->packet_allocs.insert(c->packet_allocs.end(), c->allocs.begin() + qmark, c->allocs.end());
         }
+        c->slab_end();
+        c->packet_allocs.insert(c->packet_allocs.end(), c->allocs.begin() + qmark, c->allocs.end());
         c->nframe_chunks = ntrace ? (ntrace + c->chunk_rows - 1) / c->chunk_rows : 0;
         if ((rc = c->dalloc(&c->d_scnt, (size_t)std::max(c->nframe_chunks, 1) * levels * 2))) return rc;
     }
@@ -816,7 +878,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         if (const char* e = ab_knob("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;  // 0 packets, 1 tables
         const bool can_tables = c->use_cells && c->shadow_direct;
         bool tables = can_tables;
-        if (can_tables && force < 0 && ntrace > 0 && (int64_t)c->chunk_rows * W >= ((int64_t)1 << 18) && c->S.nl > 0) {
+        if (c->form_early) {
+            tables = true;
+        } else if (can_tables && force < 0 && ntrace > 0 && (int64_t)c->chunk_rows * W >= ((int64_t)1 << 18) && c->S.nl > 0) {
             float ms[2] = {0.0f, 0.0f};
             for (int form = 0; form < 2; form++) {
                 c->use_cells = form == 1;

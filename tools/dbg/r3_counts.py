@@ -13,6 +13,10 @@ rays = st.rays_shadow
 print("shadow rays %d" % rays)
 for k, v in ex["k_shadow_pass"].items():
     if v: print("  %-12s %12d  %.2f / ray" % (k, v, v / max(rays, 1)))
+sec = st.rays_secondary
+print("secondary rays %d" % sec)
+for k, v in ex["k_closest_lanes"].items():
+    if v: print("  %-12s %12d  %.2f / ray" % (k, v, v / max(sec, 1)))
 c = rt.Context(sc, rt.Params.make(wl["width"], wl["height"], wl["max_depth"], flags=F.F_SERIAL | F.F_TIME_KERNELS))
 for _ in range(3): c.render()
 s = c.stats(); c.close()
