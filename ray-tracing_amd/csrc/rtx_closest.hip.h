@@ -711,14 +711,15 @@ constexpr int kPoolC = 64 + 64;    // (ray, cluster, group) entries: fewer than 
 constexpr int kPoolD = 64 + 64;    // (ray, primitive) entries: the same
 
 struct PoolLds {
-    float4 ray[3 * 64];            // R rays: [0, R) origin, w = flag bits (1 live, 2 abnormal); [R, 2R) normalised direction;
-                                   // [2R, 3R) direction as stored (the exact tests take both).  R = 4: [64, 192) holds the round's 128 cluster spheres
-    float4 csph[32];               // this round's cluster spheres { c, R } (R >= 16)
-    int ccid[kPoolQMax];
+    float4 ray[3 * 64];            // R rays: [0, R) origin, w = flag bits (1 live, 2 abnormal); [R, 2R) normalised direction, w = the
+                                   // ray's far limit; [2R, 3R) direction as stored (the exact tests take both).  Forms with fewer than
+                                   // 64 rays keep the round's cluster spheres { c, R } and cluster numbers behind their rays:
+                                   // R = 16: spheres [48, 80), numbers [80, 88);  R = 4: numbers [16, 48), spheres [64, 192).
+                                   // (5,696 bytes a wave: seven workgroups a CU where 6,912 gave five)
     unsigned short listB[kPoolB];  // ray << 7 | cluster slot of the round
     unsigned int listC[kPoolC];    // cluster << 9 | ray << 3 | group
     unsigned int listD[kPoolD];    // ray << 26 | primitive
-    int slot[64];                  // E: which lane delivers to ray r this step (-1 none)
+    signed char slot[64];          // E: which lane delivers to ray r this step (-1 none)
     int inK[64];                   // kind << 28 | primitive
     float inT[64];
 };
@@ -742,8 +743,9 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     const int lane = threadIdx.x & 63;
     const int myray = lane & (R - 1), part = lane / R;
     float4* const rayO = W.ray; float4* const rayN = W.ray + R; float4* const rayD = W.ray + 2 * R;
-    float4* const csph = (R * 3 <= 64 && kPoolQ > 32) ? W.ray + 64 : W.csph;
-    static_assert(kPoolQ <= 32 || (R * 3 <= 64 && kPoolQ <= 128), "the round's cluster spheres fit their LDS");
+    float4* const csph = (R == 4) ? W.ray + 64 : W.ray + 48;
+    int* const ccid = reinterpret_cast<int*>((R == 4) ? W.ray + 16 : W.ray + 80);
+    static_assert(R == 64 || (R == 16 && kPoolQ == 32) || (R == 4 && kPoolQ == 128), "the round's cluster spheres and numbers fit behind the rays");
     // ---- the wave's rays: lanes < R own one each ----
     const int q = q0 + lane;
     const bool inq = lane < R && q < n;
@@ -784,7 +786,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     // E: hand the hits of a D step to the owners of their rays, one hit per ray per round
     auto deliver = [&](bool pending, int rr, int k, float t, int kind) {
         while (__any(pending)) {
-            if (pending) W.slot[rr] = lane;
+            if (pending) W.slot[rr] = (signed char)lane;
             lds_fence();
             const bool win = pending && W.slot[rr] == lane;
             if (win) { W.inK[rr] = k | (kind << 28); W.inT[rr] = t; pending = false; }
@@ -886,7 +888,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     auto run_B = [&](int base, int cnt) {
         const bool has = lane < cnt;
         const unsigned e = W.listB[base + (has ? lane : 0)];
-        do_B(has, (int)(e >> 7), W.ccid[e & 127u]);
+        do_B(has, (int)(e >> 7), ccid[e & 127u]);
     };
 
     const int ncl = S.cseg[S.cnseg];
@@ -926,7 +928,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
 #pragma unroll
           for (int v = 0; v < kSuperRun; v++) cid[v] = S.corder[min(p0 + v, cendv - 1)];
 #pragma unroll
-          for (int v = 0; v < kSuperRun; v++) sb[v] = S.cclR[cid[v]];
+          for (int v = 0; v < kSuperRun; v++) sb[v] = S.cclRo[min(p0 + v, cendv - 1)];  // (in traversal order: no load waits on another)
           unsigned cm = 0u;
 #pragma unroll
           for (int v = 0; v < kSuperRun; v++)
@@ -996,9 +998,8 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
               }
               // ---- A: this round's cluster spheres into LDS, each lane tests its ray against its share of them ----
               for (int u = lane; u < ce; u += 64) {
-                  const int c = S.corder[cb + u];
-                  W.ccid[u] = c;
-                  csph[u] = S.cclR[c];
+                  ccid[u] = S.corder[cb + u];
+                  csph[u] = S.cclRo[cb + u];
               }
               lds_fence();
               // (bit i of cmask: this lane's i-th cluster of the round, slot part + i * kPer; at most kPoolQ / kPer <= 32 of them)
@@ -1009,14 +1010,19 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
                   if (aabn || !((front ? cone_slack_cull(ao, an, b, alr) : cone_slack(ao, an, b)) < 0.0f)) cmask |= 1u << it;
               }
               if (!alive) cmask = 0u;
-              // the pairs that passed, as a list in CLUSTER order: neighbouring lanes of a B step then read the same
-              // cluster's sub-spheres (one cache line for the lot, where a list in ray order touches 64)
+              // the pairs that passed, as a list: neighbouring lanes of a B step should read the same cluster's sub-spheres
+              // (one cache line for the lot, where a list in ray order touches 64)
+              // (every lane pushes its lowest passing cluster, as many times as the busiest lane has clusters -- 2 or 3 rounds
+              // where a loop over the round's clusters took 32 or 128; the R lanes of a part test the same cluster, so
+              // neighbouring entries of a push still name one cluster)
               int nB = 0;
-              for (int u = 0; u < ce; u++) {
-                  const bool bit = (u % kPer) == part && ((cmask >> (u / kPer)) & 1u);
+              for (;;) {
+                  const bool bit = cmask != 0u;
                   const unsigned long long bal = __ballot(bit);
-                  if (bal == 0ull) continue;  // wave-uniform
+                  if (bal == 0ull) break;  // wave-uniform
+                  const int u = part + __builtin_ctz(cmask | 0x80000000u) * kPer;
                   if (bit) W.listB[nB + lanes_below(bal)] = (unsigned short)((myray << 7) | u);
+                  cmask &= cmask - 1u;
                   nB += __popcll(bal);
               }
               lds_fence();

@@ -128,7 +128,7 @@ struct rtx_context {
     // k_closest_lanes' own cluster set (PackedScene::pc) for scenes of more than one segment; has_pc = false: S's own
     struct LanesSet {
         bool has_pc = false;
-        const float4 *cmem = nullptr, *cclR = nullptr, *csubR = nullptr, *csupR = nullptr;
+        const float4 *cmem = nullptr, *cclR = nullptr, *csubR = nullptr, *csupR = nullptr, *cclRo = nullptr;
         const int *cidx = nullptr, *cseg = nullptr, *corder = nullptr;
         int cnfirst = 0;
     } lanes;
@@ -136,7 +136,7 @@ struct rtx_context {
     {
         SceneDev SL = S;
         if (lanes.has_pc) {
-            SL.cmem = lanes.cmem; SL.cclR = lanes.cclR; SL.csubR = lanes.csubR; SL.csupR = lanes.csupR;
+            SL.cmem = lanes.cmem; SL.cclR = lanes.cclR; SL.csubR = lanes.csubR; SL.csupR = lanes.csupR; SL.cclRo = lanes.cclRo;
             SL.cidx = lanes.cidx; SL.cseg = lanes.cseg; SL.corder = lanes.corder;
             SL.cnseg = 1; SL.cnfirst = lanes.cnfirst;
         }
@@ -382,6 +382,12 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             if ((rc = c->upload(&q, P.cc.order))) return rc;
             c->S.corder = q;
             c->S.cnfirst = P.cc.nfirst;
+            auto ordered = [](const ClusterSet& cs) {
+                std::vector<BoundSphere> v(cs.order.size());
+                for (size_t p = 0; p < v.size(); p++) v[p] = cs.clR[cs.order[p]];
+                return v;
+            };
+            if ((rc = up4(ordered(P.cc), &c->S.cclRo))) return rc;
             if (!P.pc.clR.empty()) {
                 if ((rc = up4(P.pc.mem, &c->lanes.cmem))) return rc;
                 if ((rc = up4(P.pc.clR, &c->lanes.cclR))) return rc;
@@ -393,6 +399,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                 c->lanes.cseg = q;
                 if ((rc = c->upload(&q, P.pc.order))) return rc;
                 c->lanes.corder = q;
+                if ((rc = up4(ordered(P.pc), &c->lanes.cclRo))) return rc;
                 c->lanes.cnfirst = P.pc.nfirst;
                 c->lanes.has_pc = true;
             }

@@ -48,6 +48,7 @@ struct SceneDev {
     const int* corder; int cnfirst;  // per-ray traversal order of the closest-hit clusters: affine-sphere clusters first
     const float4* cclR; const float4* csubR;  // { c, R } cluster spheres [ncl] and 8 sub-cluster spheres each [ncl*8]
     const float4* csupR;          // { c, R } around every run of 8 clusters in traversal order (ClusterSet::supR)
+    const float4* cclRo;          // cclR in traversal order (cclRo[p] = cclR[corder[p]]): the per-ray traversal reads sphere and number side by side
     const float4* scl; const float4* smem; const int* sidx; int sncl;                    // shadow rays
     int sel2;                     // shadow pass: two-level member selection (frames that fill the chip; rtx_device.hip)
     const float4* ssubR;          // [sncl*8] { c, R } spheres around members 8g .. 8g+7 of every shadow cluster

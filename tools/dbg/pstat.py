@@ -1,17 +1,14 @@
+"""Packet statistics of a workload's frame (RTX_F_PACKET_STATS).  usage: pstat.py [workload]"""
 import sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtxamd as rt
-p = os.path.join(tempfile.gettempdir(), "c4dbg.txt")
-rt.scenegen.write_c4(p)
+F = rt.host
+wl = rt.scenegen.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c4"]
+p = os.path.join(tempfile.gettempdir(), "psdbg.txt")
+wl["writer"](p)
 sc = rt.load_scene(p)
-W, H = 3840, 2160
-prev = [0] * 8
-for md in (0, 1, 2, 3, 4):
-    ctx = rt.Context(sc, rt.Params.make(W, H, md, flags=rt.host.F_TIME_KERNELS | rt.host.F_PACKET_STATS))
-    ctx.render(); st = ctx.stats()
-    ps = list(st.packet_stats)
-    d = [a - b for a, b in zip(ps, prev)]; prev = ps
-    print("level %d rays %d: frame ms %.2f" % (md, st.rays_level[md], st.ms_total))
-    print("  closest: waves %d slow %d abn %d tested/ray %.1f" % (d[0], d[1] & 0xffffffff, d[1] >> 32, d[3]/max(st.rays_level[md],1)))
-    print("  shadow : blocks %d ok %d fallback rays %d batches/block %.1f survivors/block %.1f" % (d[4], d[5] & 0xffffffff, d[5] >> 32, d[6]/max(d[4],1), d[7]/max(d[4],1)))
-    ctx.close()
+c = rt.Context(sc, rt.Params.make(wl["width"], wl["height"], wl["max_depth"], flags=F.F_PACKET_STATS | F.F_SHADOW_TABLES))
+c.render(); s = c.stats(); c.close()
+ps = [int(v) for v in s.packet_stats]
+print("waves %d, ok/slow %d, abnormal lanes %d, batches %d, tested %d" % (ps[0], ps[1] & 0xffffffff, ps[1] >> 32, ps[2], ps[3]))
+print("rays per generation", [int(s.rays_level[k]) for k in range(s.levels)])
