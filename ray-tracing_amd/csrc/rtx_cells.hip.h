@@ -166,12 +166,23 @@ __device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, 
     return false;
 }
 
-// One wave per (light, cell).  FILL = false: count the entries (cnt[cell]); FILL = true: collect, sort by dneed, store.
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int2* ent, int tight)
+// One wave per (light, cell), ONE pass: collect the cell's entries in LDS, take a range of `ent` with one atomic add on the table's
+// cursor, sort by dneed, store; oc[cell] = { first entry, entries }.  Lists lie in the order the waves finish, which is why a list
+// carries its own length.  A table that does not fit `cap` entries leaves oc = { 0, 0 } for the cells that came too late and the cursor
+// at what the whole table needs: the host builds it again at that size (or takes a coarser map) -- a count pass in front, as the
+// first version had, cost as much as the fill (C4: 2.2 of 6.4 ms; context creation is inside a scene's first rtx_render_rgb8 call).
+// (Four cells a workgroup, one atomic for the four: atomics on one address are served one at a time, ~12 ns each, and a million of
+// them -- one per cell of C4's map -- took 12 ms where the build itself takes 3.)
+constexpr int kCellsPerGroup = 4;
+__global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S, int G, const float* dmax, int2* oc, int2* ent, unsigned long long* cursor,
+                                                                     unsigned long long cap, int tight)
 {
-    __shared__ int2 buf[FILL ? kCellCap : 1];
-    const int cell = blockIdx.x, lane = threadIdx.x;
+    __shared__ int2 bufs[kCellsPerGroup][kCellCap];
+    __shared__ int s_n[kCellsPerGroup];
+    __shared__ unsigned long long s_base;
+    const int wv = threadIdx.x >> 6;
+    int2* const buf = bufs[wv];
+    const int cell = blockIdx.x * kCellsPerGroup + wv, lane = threadIdx.x & 63;
     const int li = cell / (G * G), m = cell % (G * G);
     const CellCone K = cell_cone((unsigned)m, G);
     const F3 Lp = f3(S.lights[li].point);
@@ -188,8 +199,11 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
         P0.rho = delta + kExactSphereTan * (3.3f * dm) * 1.01f;  // >= every entry's own rho (rho_of below: D - s_lo + hX <= dmax + 2.1 |C|, |C| <= dmax)
     }
     const Packet& Pc = tight ? P0 : P;  // what the cluster spheres are tested with
-    const int base = FILL ? off[cell] : 0;
+    int base = 0;
     int n = 0;
+    // pass 0 collects (the first kCellCap entries in LDS); pass 1 -- only for a cell of more entries than that -- stores the rest
+    for (int pass = 0; pass < 2; pass++) {
+    n = 0;
     for (int cb = 0; cb < S.sncl; cb += 64) {
         const int c = cb + lane;
         unsigned long long cm = __ballot(c < S.sncl && packet_test(Pc, S.scl[min(c, S.sncl - 1)]));
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
             const float R = sqrtf(-mb.w) * 1.00001f;
             if (k >= 0 && !tight) {
                 keep = packet_test(P, mb);
-                if (FILL && keep) {
+                if (keep) {
                     // smallest level at which the entry passes (it passes at the last one)
                     int lo = 0, hi = kCellLevels;
                     Packet Pm = P;
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
                 Packet Pm = P0;
                 Pm.rho = rho_of(dm);
                 keep = packet_test(Pm, mb);
-                if (FILL && keep) {
+                if (keep) {
                     int lo = 0, hi = kCellLevels;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -251,24 +265,34 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
                 }
             }
             const unsigned long long bal = __ballot(keep);
-            if (FILL && keep) {
+            if (keep) {
                 // behind every origin within D of the light: n.C <= ub for every direction n of the cell
                 const float ub = (wC < 0.0f ? wC * K.cLo : wC) + h * K.sT;
                 const float dfront = -ub - 1.005f * R - 1e-3f * (Cn + dm) - 1e-3f;
                 float dneed = fmaxf(dlev, dfront);
                 if (!(R < 1e18f) || dneed != dneed) dneed = -1.0f;  // records that always pass (R = inf): every ray takes them
                 const int pos = n + lanes_below(bal);
-                if (pos < kCellCap) buf[pos] = make_int2(k, __float_as_int(dneed));
-                else ent[(size_t)base + pos] = make_int2(k, __float_as_int(-1.0f));
+                if (pass == 0) { if (pos < kCellCap) buf[pos] = make_int2(k, __float_as_int(dneed)); }
+                else if (pos >= kCellCap) ent[(size_t)base + pos] = make_int2(k, __float_as_int(-1.0f));
             }
             n += __popcll(bal);
         }
     }
-    if (!FILL) {
-        if (lane == 0) cnt[cell] = n;
-        return;
+    if (pass == 1) return;  // (the first kCellCap entries were stored after pass 0)
+    {
+        if (lane == 0) s_n[wv] = n;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < kCellsPerGroup; j++) { before += (j < wv) ? s_n[j] : 0; total += s_n[j]; }
+        if (threadIdx.x == 0) s_base = atomicAdd(cursor, (unsigned long long)total);
+        __syncthreads();
+        const unsigned long long b64 = s_base + (unsigned long long)before;
+        const bool fits = s_base + (unsigned long long)total <= cap;  // workgroup-uniform
+        if (lane == 0) oc[cell] = fits ? make_int2((int)b64, n) : make_int2(0, 0);
+        if (!fits || n == 0) return;  // (no barrier below this line)
+        base = (int)b64;
     }
-    lds_fence();
     if (n <= kCellCap) {
         // rank sort: entry i goes to the number of entries that sort before it (ties by position)
         for (int i = lane; i < n; i += 64) {
@@ -281,18 +305,10 @@ __global__ __launch_bounds__(64) void k_cells_build(SceneDev S, int G, const flo
             }
             ent[(size_t)base + rank] = e;
         }
-    } else {
-        for (int i = lane; i < kCellCap; i += 64) ent[(size_t)base + i] = make_int2(buf[i].x, __float_as_int(-1.0f));
+        return;
     }
-}
-
-// 64-bit sum of the per-cell counts (the scan kernels work in int: the host checks this against its budget first)
-__global__ __launch_bounds__(kBlock) void k_cells_sum(const int* cnt, int ncell, unsigned long long* sum)
-{
-    unsigned long long v = 0ull;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ncell; i += gridDim.x * kBlock) v += (unsigned long long)(unsigned)cnt[i];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+    for (int i = lane; i < kCellCap; i += 64) ent[(size_t)base + i] = make_int2(buf[i].x, __float_as_int(-1.0f));
+    }  // pass
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,11 +335,14 @@ __device__ __forceinline__ StripPacket cell_strip(const CellCone& K, F3 light, f
     return P;
 }
 
-// One wave per (light, cell); the lists are per (light, cell, SLAB): cnt / off are indexed by cell * kAffSlabs + slab and an
-// entry is the index of the sphere's record in aff_shadow.  Both passes run the slab tests (the count must match the fill).
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float* dmax, int* cnt, const int* off, int* ent)
+// One wave per (light, cell), one pass; the lists are per (light, cell, SLAB): oc is indexed by cell * kAffSlabs + slab and an entry
+// is the index of the sphere's record in aff_shadow.  The slab masks of the first kAffKeep * 64 spheres are kept in LDS between the
+// counting sweep and the storing sweep (the strip tests are what this kernel costs); spheres beyond that are tested again.
+constexpr int kAffKeep = 16;
+__global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float* dmax, int2* oc, int* ent, unsigned long long* cursor,
+                                                  unsigned long long cap)
 {
+    __shared__ unsigned keepm[kAffKeep][64];
     const int cell = blockIdx.x, lane = threadIdx.x;
     const int li = cell / (G * G), m = cell % (G * G);
     const CellCone K = cell_cone((unsigned)m, G);
@@ -331,14 +350,11 @@ __global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float
     const float dm = dmax[li];
     const StripPacket K0 = cell_strip(K, Lp, 0.0f, dm);
     const float slab = dm * (1.0f / (float)kAffSlabs), eps = 1e-4f * dm;
-    int mine = 0;  // lane s: entries of slab s so far
-    const int base = (FILL && lane < kAffSlabs) ? off[(size_t)cell * kAffSlabs + lane] : 0;
-    for (int a0 = 0; a0 < S.naff; a0 += 64) {
-        const int ai = min(a0 + lane, S.naff - 1);
+    auto slabs_of = [&](const int ai, const bool valid) -> unsigned {
         const float4 m0 = S.aff_shadow[(size_t)ai * 4], m1 = S.aff_shadow[(size_t)ai * 4 + 1];
         const float4 m2 = S.aff_shadow[(size_t)ai * 4 + 2], m3 = S.aff_shadow[(size_t)ai * 4 + 3];
         unsigned mask = 0u;
-        if (a0 + lane < S.naff && affine_strip_pass(K0, m0, m1, m2, m3)) {
+        if (valid && affine_strip_pass(K0, m0, m1, m2, m3)) {
             // four slabs at a time first (a wider range of D contains its slabs' packets), then the slabs of the groups that pass
             for (int g = 0; g < kAffSlabs; g += 4) {
                 const StripPacket Kg = cell_strip(K, Lp, fmaxf(0.0f, (float)g * slab - eps), (float)(g + 4) * slab + eps);
@@ -349,17 +365,48 @@ __global__ __launch_bounds__(64) void k_aff_build(SceneDev S, int G, const float
                 }
             }
         }
-        if (__ballot(mask != 0u) == 0ull) continue;  // wave-uniform
-        for (int sl = 0; sl < kAffSlabs; sl++) {
-            const bool in = (mask >> sl) & 1u;
-            const unsigned long long bal = __ballot(in);
-            if (bal == 0ull) continue;
-            const int before = __builtin_amdgcn_readlane(mine, sl), b0 = __builtin_amdgcn_readlane(base, sl);
-            if (FILL && in) ent[(size_t)b0 + before + lanes_below(bal)] = ai;
-            if (lane == sl) mine += __popcll(bal);
+        return mask;
+    };
+    int mine = 0;   // lane s: entries of slab s (sweep 0: counted; sweep 1: stored so far)
+    int base = 0;   // lane s: where slab s's list starts
+    for (int sweep = 0; sweep < 2; sweep++) {
+        for (int a0 = 0, r = 0; a0 < S.naff; a0 += 64, r++) {
+            const int ai = min(a0 + lane, S.naff - 1);
+            unsigned mask;
+            if (sweep == 1 && r < kAffKeep) mask = keepm[r][lane];
+            else mask = slabs_of(ai, a0 + lane < S.naff);
+            if (sweep == 0 && r < kAffKeep) keepm[r][lane] = mask;
+            if (__ballot(mask != 0u) == 0ull) continue;  // wave-uniform
+            for (int sl = 0; sl < kAffSlabs; sl++) {
+                const bool in = (mask >> sl) & 1u;
+                const unsigned long long bal = __ballot(in);
+                if (bal == 0ull) continue;
+                if (sweep == 1) {
+                    const int before = __builtin_amdgcn_readlane(mine, sl), b0 = __builtin_amdgcn_readlane(base, sl);
+                    if (in) ent[(size_t)b0 + before + lanes_below(bal)] = ai;
+                }
+                if (lane == sl) mine += __popcll(bal);
+            }
         }
+        if (sweep == 1) return;
+        // the cell's 32 lists take one range: lane s's list starts at the range's start + the entries of the slabs before s
+        int incl = (lane < kAffSlabs) ? mine : 0;
+        for (int d = 1; d < kAffSlabs; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, kAffSlabs - 1);
+        unsigned long long b64 = 0ull;
+        if (lane == 0) b64 = atomicAdd(cursor, (unsigned long long)total);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        b64 = ((unsigned long long)hi << 32) | lo;
+        const bool fits = b64 + (unsigned long long)total <= cap;  // wave-uniform
+        base = (int)b64 + incl - mine;
+        if (lane < kAffSlabs) oc[(size_t)cell * kAffSlabs + lane] = fits ? make_int2(base, mine) : make_int2(0, 0);
+        if (!fits || total == 0) return;
+        mine = 0;
+        lds_fence();
     }
-    if (!FILL && lane < kAffSlabs) cnt[(size_t)cell * kAffSlabs + lane] = mine;
 }
 
 struct CellsLds {
@@ -374,8 +421,8 @@ struct CellsLds {
 // (light, cell) tables: plain shadow casters { primitive, dneed } and affine spheres { record, slab mask }.
 // aoff == nullptr: no affine table (the caller runs k_shadow_affine behind the walk when the scene has affine spheres).
 struct CellTab {
-    const int* off; const int2* ent; const float* dmax; int G;
-    const int* aoff; const int* aent; int aG;   // affine lists per (light, cell, slab)
+    const int2* off; const int2* ent; const float* dmax; int G;  // off[cell] = { first entry, entries } (the lists lie in build order)
+    const int2* aoff; const int* aent; int aG;  // affine lists per (light, cell, slab), the same
     int nofilter;                                // A/B: entries go to the exact stages without the per-ray filter
 };
 
@@ -400,14 +447,16 @@ __device__ __forceinline__ bool shadow_table_trace(const SceneDev& S, const Cell
     if (covered) {
         const int cell = light_cell(nld, T.G);
         const int key = li * T.G * T.G + cell;
-        pos = T.off[key];
-        end = T.off[key + 1];
+        const int2 oc = T.off[key];
+        pos = oc.x;
+        end = oc.x + oc.y;
         if (T.aoff) {
             const int cellA = (T.aG == T.G) ? cell : light_cell(nld, T.aG);
             const int slab = min(kAffSlabs - 1, (int)(D * ((float)kAffSlabs / dm)));
             const size_t keyA = ((size_t)li * T.aG * T.aG + cellA) * kAffSlabs + slab;
-            posA = T.aoff[keyA];
-            endA = T.aoff[keyA + 1];
+            const int2 oa = T.aoff[keyA];
+            posA = oa.x;
+            endA = oa.x + oa.y;
         }
     }
     W.hit[lane] = 0;

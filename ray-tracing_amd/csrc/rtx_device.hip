@@ -490,17 +490,17 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
-            int* cnt = nullptr;
-            {
-                const size_t ncell0 = std::max((size_t)c->S.nl * G0 * G0, c->S.naff > 0 ? std::min((size_t)1 << 24, (size_t)c->S.nl * G0 * G0 * kAffSlabs) : (size_t)0);
-                HIPCHK(hipMalloc((void**)&cnt, sizeof(int) * (ncell0 + 2 * ((ncell0 + 1023) / 1024) + 2) + sizeof(unsigned long long)));
-            }
+            unsigned long long* d_cursor = nullptr;
+            HIPCHK(hipMalloc((void**)&d_cursor, sizeof(unsigned long long)));
             int cells_tight = 1;  // entries by what the exact tests can accept (rtx_cells.hip.h); 0: by what the per-ray filter can pass
             if (const char* e = ab_knob("RTX_CELL_TIGHT")) cells_tight = std::atoi(e) ? 1 : 0;
-            // count, 64-bit sum against the budget (a coarser map if it does not fit), scan, fill.  The plain table has one
-            // list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
+            // One pass per table (rtx_cells.hip.h: a wave takes its cell's range with an atomic add on a cursor): the table is
+            // allocated for a GUESS of its size -- 128 entries per caster and light for the plain table (C4 has 60, C5 85), 16,384 per
+            // affine sphere and light (C4: 14,150) -- and built again at the size the cursor reports if the guess was short; a table
+            // beyond the budget takes a coarser map (a quarter of the cells), as does one the device has no room for.  The plain table
+            // has one list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
             uint64_t tab_entries[2] = {0, 0}, tab_lists[2] = {0, 0};
-            auto build = [&](const bool affine, const int** off_out, const void** ent_out, int* G_out) -> int {
+            auto build = [&](const bool affine, const int2** off_out, const void** ent_out, int* G_out) -> int {
                 const int mult = affine ? kAffSlabs : 1;
                 const size_t esz = affine ? sizeof(int) : sizeof(int2);
                 for (int G = G0; G >= 8; G /= 2) {
@@ -509,37 +509,42 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     if ((size_t)c->S.nl * G * G * mult > (affine ? ((size_t)1 << 24) : kMaxLists)) continue;
                     const int nwave = c->S.nl * G * G;       // one build wave per (light, cell)
                     const int ncell = nwave * mult;          // lists
-                    const int nb = (ncell + 1023) / 1024;
-                    int* bsum = cnt + ncell;
-                    int* braw = bsum + nb;
-                    unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(cnt + (((size_t)ncell + 2 * (size_t)nb + 1) & ~(size_t)1));
-                    HIPCHK(hipMemset(d_sum, 0, sizeof(unsigned long long)));
-                    if (affine) hipLaunchKernelGGL(k_aff_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int*)nullptr);
-                    else hipLaunchKernelGGL(k_cells_build<false>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, (const int*)nullptr, (int2*)nullptr, cells_tight);
-                    hipLaunchKernelGGL(k_cells_sum, dim3(1024), dim3(kBlock), 0, 0, cnt, ncell, d_sum);
-                    HIPCHK(hipGetLastError());
-                    unsigned long long sum = 0;
-                    HIPCHK(hipMemcpy(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost));
-                    if (sum > max_entries) continue;  // a coarser map: a quarter of the cells
-                    const int total = (int)sum;
-                    int* off = nullptr; char* ent = nullptr;
-                    int r = c->dalloc(&ent, ((size_t)total + kCellPad) * esz);
-                    if (r == RTX_E_OOM) { (void)hipGetLastError(); continue; }  // no room for this map: a coarser one
+                    uint64_t want = (uint64_t)c->S.nl * (affine ? (uint64_t)c->S.naff * 16384 : (uint64_t)c->S.nsb * 128);
+                    want = std::min<uint64_t>(std::max<uint64_t>(want, 1 << 16), max_entries);
+                    int2* off = nullptr;
+                    int r = c->dalloc(&off, (size_t)ncell);
                     if (r) return r;
-                    if ((r = c->dalloc(&off, (size_t)ncell + 1))) return r;
-                    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, 0, cnt, off, ncell, bsum, braw, 1);
-                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, bsum, nb, off + ncell);
-                    hipLaunchKernelGGL(k_scan_add, dim3(nb * (1024 / kBlock)), dim3(kBlock), 0, 0, off, ncell, bsum, braw, 1, (float4*)nullptr);
-                    // the walks read a few entries past a list's end: plain { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
-                    HIPCHK(hipMemset(ent + (size_t)total * esz, affine ? 0 : 0xff, esz * kCellPad));
-                    if (affine) hipLaunchKernelGGL(k_aff_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int*>(ent));
-                    else hipLaunchKernelGGL(k_cells_build<true>, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, cnt, off, reinterpret_cast<int2*>(ent), cells_tight);
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipDeviceSynchronize());
-                    *off_out = off; *ent_out = ent; *G_out = G;
-                    tab_entries[affine ? 1 : 0] = (uint64_t)total; tab_lists[affine ? 1 : 0] = (uint64_t)ncell;
-                    if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: %s table G = %d, %d lists, %d entries\n", affine ? "affine" : "plain", G, ncell, total);
-                    return RTX_OK;
+                    bool coarser = false;
+                    for (int attempt = 0; attempt < 2; attempt++) {
+                        char* ent = nullptr;
+                        r = c->dalloc(&ent, ((size_t)want + kCellPad) * esz);
+                        if (r == RTX_E_OOM) { (void)hipGetLastError(); coarser = true; break; }  // no room for this map: a coarser one
+                        if (r) return r;
+                        HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), nullptr));
+                        if (affine) hipLaunchKernelGGL(k_aff_build, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int*>(ent), d_cursor, (unsigned long long)want);
+                        else hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(nwave / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int2*>(ent), d_cursor, (unsigned long long)want, cells_tight);
+                        HIPCHK(hipGetLastError());
+                        unsigned long long sum = 0;
+                        HIPCHK(hipMemcpy(&sum, d_cursor, sizeof sum, hipMemcpyDeviceToHost));  // (waits for the build)
+                        if (sum <= want) {
+                            // the walks read a few entries past a list's end: plain { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
+                            HIPCHK(hipMemset(ent + (size_t)sum * esz, affine ? 0 : 0xff, esz * kCellPad));
+                            *off_out = off; *ent_out = ent; *G_out = G;
+                            tab_entries[affine ? 1 : 0] = sum; tab_lists[affine ? 1 : 0] = (uint64_t)ncell;
+                            if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: %s table G = %d, %d lists, %llu entries (room for %llu, attempt %d)\n", affine ? "affine" : "plain", G, ncell, sum, (unsigned long long)want, attempt);
+                            return RTX_OK;
+                        }
+                        // short: give the entries back (the last allocation) and build again at the size it needs, or coarser
+                        (void)hipFree(c->allocs.back());
+                        c->allocs.pop_back();
+                        if (sum > max_entries || attempt == 1) { coarser = true; break; }
+                        want = sum;
+                    }
+                    if (coarser) {
+                        (void)hipFree(c->allocs.back());  // the offsets of this map
+                        c->allocs.pop_back();
+                        continue;
+                    }
                 }
                 return RTX_OK;  // no map is coarse enough: no table
             };
@@ -557,7 +562,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                     phase("affine table");
                 }
             }
-            (void)hipFree(cnt);
+            (void)hipFree(d_cursor);
             if (rc) return rc;
             c->cells.dmax = d_dc;
             // tight entries go straight to the exact stages: the per-ray filter in front of them rejected one pair in five and cost

@@ -21,10 +21,7 @@ template __global__ void k_shadow_affine<false, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, false, false>(SHADOW_ARGS);
 template __global__ void k_shadow_cells<false>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
 template __global__ void k_shadow_direct<false>(SceneDev, CellTab, LevelDev, const int*);
-template __global__ void k_cells_build<false>(SceneDev, int, const float*, int*, const int*, int2*, int);
-template __global__ void k_cells_build<true>(SceneDev, int, const float*, int*, const int*, int2*, int);
-template __global__ void k_aff_build<false>(SceneDev, int, const float*, int*, const int*, int*);
-template __global__ void k_aff_build<true>(SceneDev, int, const float*, int*, const int*, int*);
+// (k_cells_build and k_aff_build are not templates: this translation unit compiles them as they stand)
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 1
 template __global__ void k_shadow_pass<true, true>(SHADOW_ARGS);
