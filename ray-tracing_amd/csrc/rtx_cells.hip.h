@@ -174,8 +174,21 @@ __device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, 
 // (Four cells a workgroup, one atomic for the four: atomics on one address are served one at a time, ~12 ns each, and a million of
 // them -- one per cell of C4's map -- took 12 ms where the build itself takes 3.)
 constexpr int kCellsPerGroup = 4;
+// CAMERA mode (cam.on; round 3): the same table for the PRIMARY rays, which all leave one point as the shadow rays of a light all pass
+// through one -- apex = the camera, one "light", cells keyed by the ray's own direction, entries = every primitive (the closest-hit
+// cluster set) whose exact test can accept some ray of the cell:
+//   plain sphere   dist(c, line) <= R + 2.0e-3 |X| (above) with X = apex - c for every ray: rho = delta + 2.0e-3 |C|
+//   triangle       the ball with rho = delta, then the edge planes through the apex (tri_cell_reject), as for a light
+//   affine sphere, polygon, plane   by what the per-ray FILTER can pass (cell_packet: the cone widened by the filter's own
+//                  tolerance about the rays' common origin, rho = cell_rho(0), as k_closest_f's packet of a wave of primary rays)
+//   front          plain spheres and triangles wholly behind the apex for every direction of the cell are left out (t >= 0 only)
+// dneed carries the ORDER instead: -2 for affine spheres, -1 for the rest -- a ray tests its cell's affine spheres first (LexAcc).
+// A list longer than kCellCap, or a cell outside the view cone (cam.axis, cam.cosv: the host's bound on the frame's ray directions),
+// is marked { 0, -1 }: its rays take the scan over every primitive.
+struct CamCells { int on; F3 apex; F3 axis; float cosv, sinv; };
+
 __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S, int G, const float* dmax, int2* oc, int2* ent, unsigned long long* cursor,
-                                                                     unsigned long long cap, int tight)
+                                                                     unsigned long long cap, int tight, CamCells cam)
 {
     __shared__ int2 bufs[kCellsPerGroup][kCellCap];
     __shared__ int s_n[kCellsPerGroup];
@@ -185,10 +198,16 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
     const int cell = blockIdx.x * kCellsPerGroup + wv, lane = threadIdx.x & 63;
     const int li = cell / (G * G), m = cell % (G * G);
     const CellCone K = cell_cone((unsigned)m, G);
-    const F3 Lp = f3(S.lights[li].point);
+    const F3 Lp = cam.on ? cam.apex : f3(S.lights[li].point);
     Packet P = cell_packet(K, Lp);
     const float dm = dmax[li];
-    P.rho = cell_rho(dm);
+    P.rho = cam.on ? cell_rho(0.0f) : cell_rho(dm);
+    // camera: a cell no ray of the frame maps to is not built (angle(axis, cell axis) > view half-angle + cell half-angle)
+    const bool outside = cam.on && (K.w.x * cam.axis.x + K.w.y * cam.axis.y + K.w.z * cam.axis.z) < cam.cosv * K.cLo - cam.sinv * K.sT - 1e-4f;
+    const float4* const clu = cam.on ? S.ccl : S.scl;
+    const float4* const mem = cam.on ? S.cmem : S.smem;
+    const int* const midx = cam.on ? S.cidx : S.sidx;
+    const int nclu = outside ? 0 : (cam.on ? S.cseg[S.cnseg] : S.sncl);
     // tight entries: the cone as it is (no widening by the filter's tolerance), rho per entry
     const float delta = 2e-4f + 1e-6f * dm;
     Packet P0 = P;
@@ -204,14 +223,16 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
     // pass 0 collects (the first kCellCap entries in LDS); pass 1 -- only for a cell of more entries than that -- stores the rest
     for (int pass = 0; pass < 2; pass++) {
     n = 0;
-    for (int cb = 0; cb < S.sncl; cb += 64) {
+    for (int cb = 0; cb < nclu; cb += 64) {
         const int c = cb + lane;
-        unsigned long long cm = __ballot(c < S.sncl && packet_test(Pc, S.scl[min(c, S.sncl - 1)]));
+        // (camera: the filter-conservative packet P for the cluster test -- it contains the tight one's pass region as long as
+        // rho(P0) <= what P's widening gives, which holds for every bounded member: 2.0e-3 |C| < 3.7e-3 |C|; affine spheres need P)
+        unsigned long long cm = __ballot(c < nclu && (packet_test(Pc, clu[min(c, nclu - 1)]) || (cam.on && packet_test(P, clu[min(c, nclu - 1)]))));
         while (cm) {
             const size_t mi = (size_t)(cb + (__ffsll((long long)cm) - 1)) * 64 + lane;
             cm &= cm - 1;
-            const float4 mb = S.smem[mi];
-            const int k = S.sidx[mi];
+            const float4 mb = mem[mi];
+            const int k = midx[mi];
             bool keep = false;
             float dlev = -1.0f;
             // C = c - light; s = axial coordinate of the centre on the origins' side, h = its distance from the axis
@@ -220,9 +241,10 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
             const float wC = K.w.x * Cx + K.w.y * Cy + K.w.z * Cz;
             const float h = sqrtf(fmaxf(0.0f, C2 - wC * wC)) + 1e-3f * Cn;
             const float R = sqrtf(-mb.w) * 1.00001f;
-            if (k >= 0 && !tight) {
+            const bool loose = !tight || (cam.on && (k >= S.ns + S.nt || (k < S.ns && S.sph_xf[max(k, 0)] != 0)));
+            if (k >= 0 && loose) {
                 keep = packet_test(P, mb);
-                if (keep) {
+                if (keep && !cam.on) {
                     // smallest level at which the entry passes (it passes at the last one)
                     int lo = 0, hi = kCellLevels;
                     Packet Pm = P;
@@ -252,9 +274,9 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
                 const float hX = h + fabsf(wC) * K.sT;  // distance of the centre from a LINE of the cell (the axis turned by theta)
                 auto rho_of = [&](float D) { return delta + kExactSphereTan * ((fmaxf(D - s_lo, xmin) + hX) * 1.001f); };
                 Packet Pm = P0;
-                Pm.rho = rho_of(dm);
+                Pm.rho = cam.on ? delta + kExactSphereTan * (Cn * 1.001f + 1e-3f) : rho_of(dm);
                 keep = packet_test(Pm, mb);
-                if (keep) {
+                if (keep && !cam.on) {
                     int lo = 0, hi = kCellLevels;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -264,13 +286,16 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
                     dlev = (lo == 0) ? -1.0f : dm * ((float)(lo - 1) * (1.0f / (float)kCellLevels)) * 0.999999f;
                 }
             }
+            // behind every origin within D of the light: n.C <= ub for every direction n of the cell
+            const float ub = (wC < 0.0f ? wC * K.cLo : wC) + h * K.sT;
+            // (camera: the rays START at the apex and n is their direction -- a plain sphere or triangle with n.C + R < 0 for every n is behind them all)
+            if (cam.on && keep && !loose && ub + 1.005f * R + 1e-3f * Cn + 1e-3f < 0.0f) keep = false;
             const unsigned long long bal = __ballot(keep);
             if (keep) {
-                // behind every origin within D of the light: n.C <= ub for every direction n of the cell
-                const float ub = (wC < 0.0f ? wC * K.cLo : wC) + h * K.sT;
                 const float dfront = -ub - 1.005f * R - 1e-3f * (Cn + dm) - 1e-3f;
                 float dneed = fmaxf(dlev, dfront);
                 if (!(R < 1e18f) || dneed != dneed) dneed = -1.0f;  // records that always pass (R = inf): every ray takes them
+                if (cam.on) dneed = (k < S.ns && S.sph_xf[k] != 0) ? -2.0f : -1.0f;
                 const int pos = n + lanes_below(bal);
                 if (pass == 0) { if (pos < kCellCap) buf[pos] = make_int2(k, __float_as_int(dneed)); }
                 else if (pos >= kCellCap) ent[(size_t)base + pos] = make_int2(k, __float_as_int(-1.0f));
@@ -280,7 +305,8 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
     }
     if (pass == 1) return;  // (the first kCellCap entries were stored after pass 0)
     {
-        if (lane == 0) s_n[wv] = n;
+        const bool nolist = cam.on && (outside || n > kCellCap);   // camera: its rays take the scan over every primitive
+        if (lane == 0) s_n[wv] = nolist ? 0 : n;
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
@@ -289,8 +315,8 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
         __syncthreads();
         const unsigned long long b64 = s_base + (unsigned long long)before;
         const bool fits = s_base + (unsigned long long)total <= cap;  // workgroup-uniform
-        if (lane == 0) oc[cell] = fits ? make_int2((int)b64, n) : make_int2(0, 0);
-        if (!fits || n == 0) return;  // (no barrier below this line)
+        if (lane == 0) oc[cell] = nolist ? make_int2(0, -1) : (fits ? make_int2((int)b64, n) : make_int2(0, 0));
+        if (!fits || n == 0 || nolist) return;  // (no barrier below this line)
         base = (int)b64;
     }
     if (n <= kCellCap) {
@@ -713,6 +739,161 @@ __global__ __launch_bounds__(kBlock) void k_shadow_direct(SceneDev S, CellTab T,
     const bool done = shadow_table_trace<EX>(S, T, lds[threadIdx.x >> 6], live, o, ld, li, ex);
     if (live) L.lit[(size_t)li * L.cap + j] = done ? 0 : 1;
     ex_flush(ex, S.exec + 2 * EX_KINDS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRIMARY rays through the camera's table (round 3; k_cells_build in camera mode): one lane = one ray, which walks its cell's list
+// and hands every entry to the pooled exact stage of k_closest_lanes (closest_pool's D and E: 64 (ray, primitive) pairs at a time,
+// hits delivered to the lane that owns the ray and folded into its LexAcc, which does not depend on the order of arrival except that
+// a ray's affine spheres come first -- they lead its list, and the stage is drained between the two walks).  No packet, no cluster
+// hierarchy, no survivor broadcast: k_closest_f spent 50 ps a primary ray on C4 and 220 ps on C5 where the shadow rays, on their
+// tables, take 26 and 48.  Rays the table does not cover (abnormal, a different origin, a cell without a list) take the ordered
+// scan over every primitive, as the flagged rays of closest_pool do.
+// ------------------------------------------------------------------------------------------------
+struct CamTab { const int2* off; const int2* ent; int G; F3 apex; };
+
+struct CamLds {
+    float4 ray[3 * 64];        // origin (w: flags), normalised direction, direction as stored (w: the ray's nearest hit so far)
+    unsigned listD[64 + 64];   // ray << 26 | primitive
+    signed char slot[64];
+    int inK[64];
+    float inT[64];
+};
+
+// exact_hit with the triangle's edge filter and a bound on t (a triangle hit at t >= tmax is a miss before its three square roots)
+__device__ __forceinline__ int exact_hit_edge(const SceneDev& S, int k, F3 o, F3 d, F3 nd, float& t, const float tmax, Exec* ex)
+{
+    if (k < S.ns || k >= S.ns + S.nt) return exact_hit(S, k, o, d, nd, t, ex);
+    const float4* p = S.phot + (size_t)k * 5;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    const float4 e0 = S.tri_edge[(size_t)(k - S.ns) * 2], e1 = S.tri_edge[(size_t)(k - S.ns) * 2 + 1];
+    TriRec T;
+    T.nx = q0.x; T.ny = q0.y; T.nz = q0.z; T.d = q0.w;
+    T.vx = q1.x; T.vy = q1.y; T.vz = q1.z; T.area = q1.w;
+    T.wx = q2.x; T.wy = q2.y; T.wz = q2.z; T.v1x = q2.w;
+    T.v1y = q3.x; T.v1z = q3.y; T.v2x = q3.z; T.v2y = q3.w;
+    T.v2z = q4.x; T.ex = q4.y; T.ey = q4.z; T.ez = q4.w;
+    float vd;
+    int exitp = 0;
+    const bool hit = triangle_test_edge(o, d, T, e0, e1, t, vd, tmax, ex ? &exitp : nullptr, S.mt != 0);
+    if (ex) ex_tri(ex, exitp);
+    return hit ? 2 : 0;
+}
+
+template <bool EX>
+__global__ __launch_bounds__(kBlock) void k_primary_cells(SceneDev S, CamTab T, LevelDev L, const int* nrays)
+{
+    __shared__ CamLds lds[kBlock / 64];
+    const int n = min(*nrays, L.cap);
+    const int base = blockIdx.x * kBlock;
+    if (base >= n) return;  // block-uniform
+    Exec exs;
+    Exec* ex = EX ? &exs : nullptr;
+    ex_zero(ex);
+    CamLds& W = lds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int q = base + threadIdx.x;
+    const bool inq = q < n;
+    const int i = inq ? q : 0;
+    const F3 o = f3(L.ox[i], L.oy[i], L.oz[i]);
+    const F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
+    const F3 nd = normalized(d);
+    const bool live = inq && !ray_dead(o, d);
+    const bool abn = live && ray_abnormal(o, d, nd, S.guard);
+    const bool zero_dir = d.x == 0.0f && d.y == 0.0f && d.z == 0.0f;
+    if (lane == 0) ex_add(ex, EX_WAVES);
+    if (inq) ex_add(ex, EX_RAYS);
+    float4* const rayO = W.ray; float4* const rayN = W.ray + 64; float4* const rayD = W.ray + 128;
+    rayO[lane] = make_float4(o.x, o.y, o.z, 0.0f);
+    rayN[lane] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    rayD[lane] = make_float4(d.x, d.y, d.z, kMaxT);
+    W.slot[lane] = -1;
+    // the ray's list
+    int pos = 0, end = 0;
+    bool covered = live && !abn && !zero_dir && o.x == T.apex.x && o.y == T.apex.y && o.z == T.apex.z;
+    if (covered) {
+        const int2 oc = T.off[light_cell(nd, T.G)];
+        pos = oc.x; end = oc.x + oc.y;
+        if (oc.y < 0) { covered = false; end = pos; }
+    }
+    lds_fence();
+    LexAcc h;
+    h.nearest = kMaxT; h.best = -1; h.overflow = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) { h.ak[e] = -1; h.at[e] = 0.0f; }
+    int nD = 0;
+    auto deliver = [&](bool pending, int rr, int k, float t, int kind) {
+        while (__any(pending)) {
+            if (pending) W.slot[rr] = (signed char)lane;
+            lds_fence();
+            const bool win = pending && W.slot[rr] == lane;
+            if (win) { W.inK[rr] = k | (kind << 28); W.inT[rr] = t; pending = false; }
+            lds_fence();
+            if (W.slot[lane] >= 0) {
+                const int e = W.inK[lane];
+                lex_update(h, e & ((1 << 28) - 1), W.inT[lane], e >> 28);
+                W.slot[lane] = -1;
+                rayD[lane].w = h.nearest;
+            }
+            lds_fence();
+        }
+    };
+    auto run_D = [&](const int want) {
+        const int cnt = min(want, nD), b0 = nD - cnt;
+        const bool has = lane < cnt;
+        const unsigned e = W.listD[b0 + (has ? lane : 0)];
+        const int k = (int)(e & ((1u << kPoolPrimBits) - 1u));
+        const int rr = (int)(e >> kPoolPrimBits);
+        const float4 rO = rayO[rr], rN = rayN[rr], rD = rayD[rr];
+        float t = 0.0f;
+        int kind = 0;
+        // (rD.w: the ray's nearest hit as its owner last wrote it: a triangle matters only at t < nearest, or at t == nearest with a
+        // lower index -- everything at t >= the float above nearest leaves early)
+        if (has) kind = exact_hit_edge(S, k, f3(rO.x, rO.y, rO.z), f3(rD.x, rD.y, rD.z), f3(rN.x, rN.y, rN.z), t, __int_as_float(__float_as_int(rD.w) + 1), ex);
+        nD = b0;
+        deliver(kind != 0, rr, k, t, kind);
+    };
+    const int kAffKey = __float_as_int(-2.0f);
+    for (int walk = 0; walk < 2; walk++) {
+        // walk 0: the affine spheres at the head of every list; walk 1: the rest
+        for (;;) {
+            int2 e = make_int2(-1, 0);
+            if (pos < end) e = T.ent[pos];
+            const bool take = pos < end && e.x >= 0 && (walk == 1 || e.y == kAffKey);
+            const unsigned long long bal = __ballot(take);
+            if (bal == 0ull) break;  // wave-uniform
+            if (take) { W.listD[nD + lanes_below(bal)] = ((unsigned)lane << kPoolPrimBits) | (unsigned)e.x; pos++; }
+            nD += __popcll(bal);
+            lds_fence();
+            if (nD >= 64) run_D(64);
+        }
+        while (nD > 0) run_D(nD);
+    }
+    bool aliveList = false;
+#pragma unroll
+    for (int e = 0; e < kAffList; e++) aliveList = aliveList || h.ak[e] >= 0;
+    float nearest = h.nearest;
+    int best = h.best;
+    int tflag = (best >= 0 && best < S.ns && aliveList) ? kTFlag : 0;
+    const bool slow = live && (h.overflow || !covered);
+    if (__any(slow)) {
+        const F3 fo = abn ? f3(1e18f, 0.0f, 0.0f) : o;
+        const F3 fd = abn ? f3(0.0f, 0.0f, 0.0f) : f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale);
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        const int nprim = S.ns + S.nt + S.np;
+        for (int k = 0; k < nprim; k++) {
+            const float4 b = S.bounds[k];
+            if (slow && !abn) ex_add(ex, EX_FILT);
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs, ex);
+        }
+        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+    }
+    if (inq) {
+        L.t[i] = nearest;
+        L.prim[i] = (best < 0) ? -1 : (best | tflag);
+    }
+    ex_flush(ex, S.exec + 0 * EX_KINDS);
 }
 
 }  // namespace rtx

@@ -149,6 +149,8 @@ struct rtx_context {
     std::vector<hipEvent_t> kev;            // RTX_F_TIME_KERNELS: (start, stop) per hot launch
     std::vector<int> kev_kind;              // 0 closest (packet / exact), 1 shadow, 2 closest per-ray; per pair used by the last render
     hipStream_t last_stream = nullptr;
+    CamTab cam{};                           // camera direction cell -> primitives (k_primary_cells, rtx_cells.hip.h); off == nullptr: generation 0
+                                            // takes k_closest_f
     CellTab cells{};                        // (light, direction cell) -> shadow casters (rtx_cells.hip.h); off == nullptr: no table,
                                             // the packet kernels (k_shadow_pass) trace the plain primitives
     bool shadow_direct = false;             // the table kernels read the hit records themselves: no shadow queue, no sort (k_shadow_direct)
@@ -522,7 +524,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
                         if (r) return r;
                         HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), nullptr));
                         if (affine) hipLaunchKernelGGL(k_aff_build, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int*>(ent), d_cursor, (unsigned long long)want);
-                        else hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(nwave / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int2*>(ent), d_cursor, (unsigned long long)want, cells_tight);
+                        else hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(nwave / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int2*>(ent), d_cursor, (unsigned long long)want, cells_tight, CamCells{});
                         HIPCHK(hipGetLastError());
                         unsigned long long sum = 0;
                         HIPCHK(hipMemcpy(&sum, d_cursor, sizeof sum, hipMemcpyDeviceToHost));  // (waits for the build)
@@ -617,6 +619,95 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         c->C.vpn = {P.vpn.x, P.vpn.y, P.vpn.z};
         c->C.camera = {P.camera.x, P.camera.y, P.camera.z};
         c->C.orig = {P.orig.x, P.orig.y, P.orig.z};
+        // ---- the camera's table: primary rays all leave C.orig, so which primitives one of them can hit is a function of its
+        //      direction alone (rtx_cells.hip.h, camera mode).  Built for the cells inside the frame's view cone only. ----
+        c->cam = CamTab{};
+        bool want_cam = !c->arena && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS)) && c->S.cseg && c->S.cseg != nullptr &&
+                        !P.cc.cl.empty();
+        if (const char* e = ab_knob("RTX_CAM")) want_cam = want_cam && std::atoi(e) != 0;
+        if (want_cam) {
+            // the view cone: the four corner rays as k_raygen forms them (double precision here, 1e-4 of slack on the cosine)
+            auto dir_of = [&](int x, int y, double out[3]) {
+                const double a = (double)P.imagex[x] - P.camera.x, b = (double)P.imagey[y] - P.camera.y, cz = -(double)P.camera.z;
+                double v[3] = {a * P.ncrossv.x + b * P.up.x + cz * P.vpn.x, a * P.ncrossv.y + b * P.up.y + cz * P.vpn.y, a * P.ncrossv.z + b * P.up.z + cz * P.vpn.z};
+                const double nn = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                for (int q = 0; q < 3; q++) out[q] = nn > 0 ? v[q] / nn : 0.0;
+            };
+            double cr[4][3], ax[3] = {0, 0, 0};
+            dir_of(0, 0, cr[0]); dir_of(W - 1, 0, cr[1]); dir_of(0, H - 1, cr[2]); dir_of(W - 1, H - 1, cr[3]);
+            for (auto& v : cr) for (int q = 0; q < 3; q++) ax[q] += v[q];
+            const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            double cosv = 1.0;
+            for (auto& v : cr) cosv = std::min(cosv, (v[0] * ax[0] + v[1] * ax[1] + v[2] * ax[2]) / (an > 0 ? an : 1.0));
+            cosv -= 1e-4;
+            if (!(an > 1e-6) || !std::isfinite(cosv) || cosv < -1.0) { cosv = -1.0; ax[0] = 0; ax[1] = 0; ax[2] = an > 1e-6 ? an : 1.0; }  // no usable cone: every cell
+            CamCells cm{};
+            cm.on = 1;
+            cm.apex = {P.orig.x, P.orig.y, P.orig.z};
+            cm.axis = {(float)(ax[0] / (an > 1e-6 ? an : 1.0)), (float)(ax[1] / (an > 1e-6 ? an : 1.0)), (float)(ax[2] / (an > 1e-6 ? an : 1.0))};
+            cm.cosv = (float)cosv;
+            cm.sinv = (float)std::sqrt(std::max(0.0, 1.0 - cosv * cosv)) + 1e-4f;
+            // range: the far corner of the scene box from the camera (the entries' rho is per entry; this scales the absolute slack)
+            double far2 = 0;
+            {
+                const float lp[3] = {P.orig.x, P.orig.y, P.orig.z};
+                const float lo[3] = {c->S.box_lo.x, c->S.box_lo.y, c->S.box_lo.z};
+                const float inv[3] = {c->S.box_inv.x, c->S.box_inv.y, c->S.box_inv.z};
+                for (int a = 0; a < 3; a++) {
+                    const double hi = (double)lo[a] + 16.0 / (double)inv[a];
+                    const double dd = std::max(std::fabs((double)lp[a] - lo[a]), std::fabs((double)lp[a] - hi));
+                    far2 += dd * dd;
+                }
+            }
+            const double rng = std::sqrt(far2) * 1.01 + 1.0;
+            const bool apex_ok = std::isfinite(rng) && rng < 1e15 && std::isfinite(P.orig.x) && std::isfinite(P.orig.y) && std::isfinite(P.orig.z);
+            std::vector<float> dcam(1, apex_ok ? (float)rng : 0.0f);
+            float* d_dcam = nullptr;
+            if (apex_ok && (rc = c->upload(&d_dcam, dcam))) return rc;
+            int Gc = 1024;
+            if (const char* e = ab_knob("RTX_CAM_G")) Gc = std::max(8, std::min(4096, std::atoi(e)));
+            const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
+            const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
+            const uint64_t nprim_all = (uint64_t)P.bounds.size();
+            unsigned long long* d_cursor = nullptr;
+            if (apex_ok) HIPCHK(hipMalloc((void**)&d_cursor, sizeof(unsigned long long)));
+            for (int G = Gc; apex_ok && G >= 64 && !c->cam.off; G /= 2) {
+                const int ncell = G * G;
+                uint64_t want = std::min<uint64_t>(std::max<uint64_t>(nprim_all * 256, (uint64_t)1 << 20), max_entries);
+                int2* off = nullptr;
+                int r = c->dalloc(&off, (size_t)ncell);
+                if (r) { (void)hipFree(d_cursor); return r; }
+                bool coarser = false;
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    int2* ent = nullptr;
+                    r = c->dalloc(&ent, (size_t)want + kCellPad);
+                    if (r == RTX_E_OOM) { (void)hipGetLastError(); coarser = true; break; }
+                    if (r) { (void)hipFree(d_cursor); return r; }
+                    HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), nullptr));
+                    hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(ncell / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dcam, off, ent, d_cursor,
+                                       (unsigned long long)want, 1, cm);
+                    HIPCHK(hipGetLastError());
+                    unsigned long long sum = 0;
+                    HIPCHK(hipMemcpy(&sum, d_cursor, sizeof sum, hipMemcpyDeviceToHost));
+                    if (sum <= want) {
+                        HIPCHK(hipMemset(ent + sum, 0xff, sizeof(int2) * kCellPad));
+                        c->cam.off = off; c->cam.ent = ent; c->cam.G = G; c->cam.apex = cm.apex;
+                        if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: camera table G = %d, %llu entries (room for %llu, attempt %d), view cone cos %.4f\n", G, sum, (unsigned long long)want, attempt, cosv);
+                        break;
+                    }
+                    (void)hipFree(c->allocs.back());
+                    c->allocs.pop_back();
+                    if (sum > max_entries || attempt == 1) { coarser = true; break; }
+                    want = sum;
+                }
+                if (coarser) {
+                    (void)hipFree(c->allocs.back());
+                    c->allocs.pop_back();
+                }
+            }
+            if (d_cursor) (void)hipFree(d_cursor);
+            phase("camera table");
+        }
     }
     if ((rc = c->upload(&c->d_trace_rows, c->trace_rows))) return rc;
     if ((rc = c->upload(&c->d_row2ti, c->row2ti))) return rc;
@@ -1012,6 +1103,10 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
                 const dim3 gl(std::max(g, grid_lanes_thin(live_cap, c->lanes16, c->lanes4)));
                 if (exec) hipLaunchKernelGGL(k_closest_lanes<true>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
                 else hipLaunchKernelGGL(k_closest_lanes<false>, gl, dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
+            }
+            else if (c->cam.off) {
+                if (exec) hipLaunchKernelGGL(k_primary_cells<true>, dim3(g), dim3(kBlock), 0, st, c->S, c->cam, Lk, rays + k);
+                else hipLaunchKernelGGL(k_primary_cells<false>, dim3(g), dim3(kBlock), 0, st, c->S, c->cam, Lk, rays + k);
             }
             else if (live_cap < kPrefetchRays) {
                 if (exec) hipLaunchKernelGGL((k_closest_f<true, true>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);

@@ -21,6 +21,7 @@ template __global__ void k_shadow_affine<false, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<false, false, false>(SHADOW_ARGS);
 template __global__ void k_shadow_cells<false>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
 template __global__ void k_shadow_direct<false>(SceneDev, CellTab, LevelDev, const int*);
+template __global__ void k_primary_cells<false>(SceneDev, CamTab, LevelDev, const int*);
 // (k_cells_build and k_aff_build are not templates: this translation unit compiles them as they stand)
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 1
@@ -31,6 +32,7 @@ template __global__ void k_shadow_affine<true, true, false>(SHADOW_ARGS);
 template __global__ void k_shadow_affine<true, false, false>(SHADOW_ARGS);
 template __global__ void k_shadow_cells<true>(SceneDev, CellTab, ShadowQ, const int*, unsigned char*, int);
 template __global__ void k_shadow_direct<true>(SceneDev, CellTab, LevelDev, const int*);
+template __global__ void k_primary_cells<true>(SceneDev, CamTab, LevelDev, const int*);
 #endif
 #if !defined(VERIFY_PART) || VERIFY_PART == 2
 template __global__ void k_closest_f<false, false>(SceneDev, LevelDev, const int*);
