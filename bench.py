@@ -145,6 +145,8 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
                      "kernels' executed FLOPs / the timed (overlapped) frame.  Set-up, sort, shading and antialias FLOPs are not credited.  "
                      "reference_test_flops / useful_frac = the same with only the reference's own tests credited (SURVEY.md 8d: sphere, "
                      "affine sphere, triangle; none of the culling tests in front of them).  "
+                     "k_closest_f = generation 0's closest hit: k_primary_cells (the camera's direction-cell table) where a context has "
+                     "that table, the packet kernel k_closest_f where it has not.  "
                      "k_shadow_pass = one timed bracket per generation: form 'tables' = ONE launch, k_shadow_direct (plain primitives and affine "
                      "spheres through the (light, cell) tables, straight off the hit records); form 'packets' = the traversal kernel "
                      "k_shadow_pass plus the affine-sphere kernel k_shadow_affine behind it, over the sorted queue.")
@@ -183,7 +185,8 @@ def roofline(rt, make_ctx, stream, st_timed, args, W, H, wl, world):
         src, rows = pmc_summary(args.workload)
         frames, tot_valu = None, 0.0
         # the timed bracket of a shadow generation holds the traversal kernel AND the affine-sphere kernel behind it
-        group = ("k_shadow_pass", "k_shadow_cells", "k_shadow_direct", "k_shadow_affine") if dom == "k_shadow_pass" else (dom,)
+        group = (("k_shadow_pass", "k_shadow_cells", "k_shadow_direct", "k_shadow_affine") if dom == "k_shadow_pass" else
+                 ("k_closest_f", "k_primary_cells") if dom == "k_closest_f" else (dom,))
         acc = {}
         for row in rows:
             name = row["kernel"].replace("rtx::", "")
@@ -404,8 +407,9 @@ def main():
                              "one_shot_rtx_render_rgb8_next_call_ms": (t3 - t2) * 1e3,
                              "note": "value above is the resident render with the frame left in HBM; these add the 24.9 MB device-to-host "
                                      "copy (through the context's pinned staging buffer into the caller's pageable one), and for the one-shot drop-in call: "
-                                     "context creation (scene pack + upload, (light, cell) tables, queue allocation, calibration pass, the timed "
-                                     "choice between the two forms of the shadow stage) on its first call, a hash of the scene on the next"}
+                                     "context creation (scene pack + upload, the lights' and the camera's direction-cell tables, calibration pass, queue "
+                                     "allocation; the timed choice between the two forms of the shadow stage only where the tables' lists are long) "
+                                     "on its first call, a hash of the scene on the next"}
     if world > 1:
         dist.barrier()
     if rank == 0:

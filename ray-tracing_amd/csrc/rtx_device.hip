@@ -664,7 +664,9 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             std::vector<float> dcam(1, apex_ok ? (float)rng : 0.0f);
             float* d_dcam = nullptr;
             if (apex_ok && (rc = c->upload(&d_dcam, dcam))) return rc;
-            int Gc = 1024;
+            // cells a side: 512, and 1,024 for dense scenes as the lights' tables take (C4: 2.271 / 2.268 / 2.254 ms per frame with 512 /
+            // 1,024 / 2,048, building them 1.6 / 4.9 / 17 ms; C5, 100,000 triangles: 33.2 / 32.7 / 32.6 ms per frame)
+            int Gc = (c->S.nsb >= 32768) ? 1024 : 512;
             if (const char* e = ab_knob("RTX_CAM_G")) Gc = std::max(8, std::min(4096, std::atoi(e)));
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
