@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <string>
@@ -622,8 +623,13 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         // ---- the camera's table: primary rays all leave C.orig, so which primitives one of them can hit is a function of its
         //      direction alone (rtx_cells.hip.h, camera mode).  Built for the cells inside the frame's view cone only. ----
         c->cam = CamTab{};
-        bool want_cam = !c->arena && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS)) && c->S.cseg && c->S.cseg != nullptr &&
-                        !P.cc.cl.empty();
+        bool want_cam = !c->arena && ntrace > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS)) && c->S.cseg != nullptr && !P.cc.cl.empty();
+        {   // records that always pass (polygons, planes, affine spheres with a translation row) sit in EVERY list: a scene with
+            // hundreds of them keeps the packet kernel, whose hierarchy holds them once
+            size_t unbounded = 0;
+            for (const BoundSphere& b : P.bounds) unbounded += (b.neg_r2 == -std::numeric_limits<float>::infinity()) ? 1 : 0;
+            if (unbounded > 256) want_cam = false;
+        }
         if (const char* e = ab_knob("RTX_CAM")) want_cam = want_cam && std::atoi(e) != 0;
         if (want_cam) {
             // the view cone: the four corner rays as k_raygen forms them (double precision here, 1e-4 of slack on the cosine)
