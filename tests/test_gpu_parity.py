@@ -276,3 +276,63 @@ def test_edge_scenes(rt, oracle, gpu, tmp_path, name, size):
         rgb_gpu, _ = rt.render_rgb8(sc, rt.Params.make(W, H, 4))
         rgb_cpu, _ = oracle.render_rgb8(sc, W, H, 4)
         assert_rgb8_parity(rgb_gpu, rgb_cpu, name)
+
+
+def _camera_case(kind):
+    """Scene text for test_camera_table_cases (HEAD grammar: first line = number of records)."""
+    rng = np.random.default_rng(77)
+    cam = "0 0 -0.1" if kind == "wide" else "0 0 -1"
+    head = "camera %s\nvrp 0 0 0\nvpn 0 0 -1\nup 0 1 0\nambient 0.1 0.2 0.3\n" % cam
+    rec = ["light 3 8 -2 1 1 1", "light -20 5 30 0.5 0.5 0.5"]
+    mat = "1 1 1  .8 .8 .8  .4 .4 .4"
+    if kind in ("inside", "wide"):
+        # primitives on every side of the camera, also behind it and around it; a few affine spheres, reflective ones
+        for i in range(400):
+            c = rng.uniform(-50, 50, 3)
+            r = float(rng.uniform(0.5, 4.0))
+            xf = i % 7 == 0
+            s = "sphere %.4f %.4f %.4f %.4f  %s  %s 1.3 %d 8" % (c[0], c[1], c[2], r, mat, "0.5 0" if i % 3 == 0 else "0 0", 1 if xf else 0)
+            if xf:
+                s += "  %.3f 0 0  0 %.3f 0  0 0 %.3f  0 0 0" % tuple(rng.uniform(0.6, 1.8, 3))
+            rec.append(s)
+        for i in range(300):
+            v = rng.uniform(-50, 50, 3)
+            e = rng.uniform(-6, 6, (2, 3))
+            rec.append("triangle %.4f %.4f %.4f  %.4f %.4f %.4f  %.4f %.4f %.4f  %s  %s 1 8" %
+                       (v[0], v[1], v[2], *(v + e[0]), *(v + e[1]), mat, "0.5 0" if i % 4 == 0 else "0 0"))
+        rec.append("sphere 0 0 0 30  %s  0 0 1 0 8" % mat)   # the camera sits inside this one
+        rec.append("polygon 4 -6 -3 -6  6 -3 -6  6 -3 -40  -6 -3 -40  %s  0.5 0 1 8" % mat)
+    elif kind == "long_list":
+        # 2,500 small spheres behind one another: the middle cells' lists exceed what a build wave sorts (their rays take the scan)
+        for i in range(2500):
+            rec.append("sphere %.4f %.4f %.4f 0.3  %s  %s 1 0 8" % (rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), -5.0 - 0.1 * i, mat, "0.5 0" if i % 50 == 0 else "0 0"))
+    elif kind == "many_polygons":
+        # 300 records no filter bounds: the camera table is not built, generation 0 keeps the packet kernel
+        for i in range(300):
+            x, y, z = rng.uniform(-30, 30), rng.uniform(-20, 20), rng.uniform(-90, -20)
+            rec.append("polygon 4 %.3f %.3f %.3f  %.3f %.3f %.3f  %.3f %.3f %.3f  %.3f %.3f %.3f  %s  %s 1 8" %
+                       (x, y, z, x + 2, y, z, x + 2, y + 2, z, x, y + 2, z, mat, "0.5 0" if i % 5 == 0 else "0 0"))
+        for i in range(50):
+            c = rng.uniform(-30, 30, 3)
+            rec.append("sphere %.4f %.4f %.4f 2  %s  0.5 0 1 0 8" % (c[0], c[1], c[2] - 50, mat))
+    return "%d\n" % len(rec) + head + "\n".join(rec) + "\n"
+
+
+@pytest.mark.parametrize("kind", ["inside", "wide", "long_list", "many_polygons"])
+def test_camera_table_cases(rt, gpu, tmp_path, kind):
+    """The primary rays' direction-cell table (k_primary_cells) where its construction has a case of its own:
+    the camera inside the scene and inside a sphere (primitives behind the apex, the front cull), a view cone of more than
+    150 degrees, a cell whose list is too long to sort (its rays take the scan over every primitive), a scene with hundreds of
+    always-pass records (no table: the packet kernel).  Default kernels against the exact-only kernels, bit for bit, whole
+    frames and a rank's bands."""
+    p = tmp_path / ("cam_%s.txt" % kind)
+    p.write_text(_camera_case(kind))
+    sc = rt.load_scene(str(p))
+    W, H = (96, 54) if kind == "long_list" else (480, 270)
+    for extra in ({}, {"nranks": 3, "rank": 1, "band_rows": 5}):
+        a, sa = rt.render_f32(sc, rt.Params.make(W, H, 3, **extra))
+        b, sb = rt.render_f32(sc, rt.Params.make(W, H, 3, flags=rt.host.F_EXACT_ONLY, **extra))
+        same = raw_equal_mask(a, b)
+        assert same.all(), "%s %s: %d pixels differ" % (kind, extra, int((~same).sum()))
+        assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+        assert sa.hits > 0 or extra
