@@ -297,7 +297,8 @@ int  rtx_affine_shadow_records(const rtx_scene* scene, float* out16, int32_t cap
 int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capacity);
 
 /* The cluster hierarchy the traversal kernels walk (rtx_pack.cpp: build_clusters): which = 0, the closest-hit set over
- * the records of rtx_filter_records; which = 1, the shadow set (plain spheres and triangles).  Returns the number of
+ * the records of rtx_filter_records; which = 1, the shadow set (plain spheres and triangles); which = 2, the set the per-ray
+ * traversal walks (its own unsegmented one in scenes of more than 16,384 primitives, else set 0).  Returns the number of
  * clusters ncl; with non-NULL outputs (capacity in clusters, >= ncl) it fills
  *   cluster4 [ncl * 4]       { c.x, c.y, c.z, R }   the cluster spheres (R = +inf: always passes),
  *   sub4     [ncl * 8 * 4]   { c, R }               the spheres around members 8s .. 8s+7 of every cluster,
@@ -308,6 +309,15 @@ int  rtx_triangle_edge_records(const rtx_scene* scene, float* out8, int32_t capa
  * cluster's.  No counterpart in the reference. */
 int  rtx_cluster_records(const rtx_scene* scene, int32_t which, float* cluster4, float* sub4, float* member4,
                          int32_t* index, int32_t capacity);
+
+/* The per-ray traversal's order and run spheres of cluster set `which` (as rtx_cluster_records): order [ncl] = the clusters in
+ * traversal order, the first *nfirst_out of them the clusters of affine spheres; run4 [*nruns_out * 4] = { c, R } around every
+ * run of 8 consecutive clusters of that order, the affine-first part and the rest counted apart (R = +inf: always passes).
+ * k_closest_lanes skips a run whose sphere a ray's cone misses or that lies wholly beyond the ray's far limit, so every
+ * cluster sphere must lie inside its run's (tests/test_clusters.py).  capacity in entries, >= ncl; returns ncl.  No
+ * counterpart in the reference. */
+int  rtx_cluster_runs(const rtx_scene* scene, int32_t which, int32_t* order, float* run4, int32_t capacity, int32_t* nfirst_out,
+                      int32_t* nruns_out);
 
 /* The direction map of the shadow stage (rtx_shadow.hip.h: light_cell; rtx_cells.hip.h: cell_cone), the kernels' own functions
  * compiled for the host.  rtx_light_cell: the cell (Morton index, 0 .. G*G-1) of the G x G octahedral map a direction falls

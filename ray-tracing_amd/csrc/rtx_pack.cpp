@@ -537,11 +537,12 @@ extern "C" int rtx_cluster_records(const rtx_scene* scene, int32_t which, float*
 {
     int rc = rtx::validate_scene(scene);
     if (rc) return rc;
-    if (which != 0 && which != 1) return RTX_E_INVALID_ARG;
+    if (which < 0 || which > 2) return RTX_E_INVALID_ARG;
     RTX_PACK_TRY
     rtx::PackedScene P;
     rtx::pack_scene(*scene, 1, 1, P, 0u);
-    const rtx::ClusterSet& cs = which ? P.sc : P.cc;
+    // which = 2: the set k_closest_lanes walks -- its own unsegmented one for scenes of more than one segment, else the closest-hit set
+    const rtx::ClusterSet& cs = which == 1 ? P.sc : (which == 2 && !P.pc.clR.empty()) ? P.pc : P.cc;
     const int ncl = (int)cs.clR.size();
     if ((cluster4 || sub4 || member4 || index) && capacity < ncl) return RTX_E_INVALID_ARG;
     static_assert(sizeof(rtx::BoundSphere) == 16, "4 floats");
@@ -549,6 +550,26 @@ extern "C" int rtx_cluster_records(const rtx_scene* scene, int32_t which, float*
     if (sub4 && ncl) std::memcpy(sub4, cs.subR.data(), (size_t)ncl * 8 * 16);
     if (member4 && ncl) std::memcpy(member4, cs.mem.data(), (size_t)ncl * rtx::kClusterSize * 16);
     if (index && ncl) std::memcpy(index, cs.idx.data(), (size_t)ncl * rtx::kClusterSize * sizeof(int32_t));
+    return ncl;
+    RTX_PACK_CATCH
+}
+
+extern "C" int rtx_cluster_runs(const rtx_scene* scene, int32_t which, int32_t* order, float* run4, int32_t capacity, int32_t* nfirst_out,
+                                int32_t* nruns_out)
+{
+    int rc = rtx::validate_scene(scene);
+    if (rc) return rc;
+    if (which < 0 || which > 2) return RTX_E_INVALID_ARG;
+    RTX_PACK_TRY
+    rtx::PackedScene P;
+    rtx::pack_scene(*scene, 1, 1, P, 0u);
+    const rtx::ClusterSet& cs = which == 1 ? P.sc : (which == 2 && !P.pc.clR.empty()) ? P.pc : P.cc;
+    const int ncl = (int)cs.order.size(), nruns = (int)cs.supR.size();
+    if ((order || run4) && (capacity < ncl || capacity < nruns)) return RTX_E_INVALID_ARG;
+    if (order && ncl) std::memcpy(order, cs.order.data(), (size_t)ncl * sizeof(int32_t));
+    if (run4 && nruns) std::memcpy(run4, cs.supR.data(), (size_t)nruns * 16);
+    if (nfirst_out) *nfirst_out = cs.nfirst;
+    if (nruns_out) *nruns_out = nruns;
     return ncl;
     RTX_PACK_CATCH
 }

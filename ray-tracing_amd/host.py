@@ -143,6 +143,7 @@ SYMBOLS = {
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_cluster_records": (C.c_int, [C.POINTER(SceneView), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "rtx_cluster_runs": (C.c_int, [C.POINTER(SceneView), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_load_legacy": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_free": (None, [C.POINTER(SceneView)]),
@@ -284,6 +285,17 @@ def cluster_records(scene, which=0):
         _check(lib().rtx_cluster_records(scene.ptr, which, cl.ctypes.data, sub.ctypes.data, mem.ctypes.data, idx.ctypes.data, n),
                "rtx_cluster_records")
     return cl, sub, mem, idx
+
+
+def cluster_runs(scene, which=0):
+    """(order[ncl], run[nruns,4], nfirst): the per-ray traversal's cluster order, the { c, R } spheres around its runs of 8
+    clusters (affine-first part and the rest counted apart) and the number of affine-sphere clusters (rtx_cluster_runs)."""
+    nf, nr = C.c_int32(0), C.c_int32(0)
+    n = _check(lib().rtx_cluster_runs(scene.ptr, which, None, None, 0, C.byref(nf), C.byref(nr)), "rtx_cluster_runs")
+    order = np.zeros(n, dtype=np.int32); run = np.zeros((nr.value, 4), dtype=np.float32)
+    if n:
+        _check(lib().rtx_cluster_runs(scene.ptr, which, order.ctypes.data, run.ctypes.data, max(n, nr.value), C.byref(nf), C.byref(nr)), "rtx_cluster_runs")
+    return order, run, nf.value
 
 
 def affine_shadow_records(scene):

@@ -27,7 +27,7 @@ def _check_set(scene, which):
     slots = idx[idx >= 0]
     assert len(np.unique(slots)) == len(slots), "a primitive sits in two member slots"
     can_pass = ~(rec[:, 3] == np.inf)  # -R^2 = +inf: the record rejects every ray, the primitive is in no cluster
-    if which == 0:
+    if which != 1:
         want = set(np.nonzero(can_pass)[0].tolist())
     else:  # shadow casters: plain spheres and triangles (affine spheres have their own records, polygons cast none)
         plain = np.array([not scene.view.spheres[i].istransformed for i in range(ns)], dtype=bool)
@@ -103,5 +103,59 @@ def test_degenerate_inputs():
     sc = rt.load_scene(p)
     for which in (0, 1):
         _check_set(sc, which)
+    sc.close()
+    os.remove(p)
+
+
+def _check_runs(scene, which):
+    """The run spheres the per-ray traversal culls on (rtx_cluster_runs): `order` is a permutation of the clusters with the
+    clusters that hold affine spheres first, and every cluster's sphere lies inside the sphere of its run of 8 (an unbounded
+    cluster makes its run unbounded)."""
+    cl, _sub, _mem, idx = rt.cluster_records(scene, which)
+    order, run, nfirst = rt.cluster_runs(scene, which)
+    ncl = cl.shape[0]
+    assert sorted(order.tolist()) == list(range(ncl))
+    ns = scene.view.nspheres
+    aff = np.array([bool(scene.view.spheres[i].istransformed) for i in range(ns)], dtype=bool)
+    if which != 1:   # (the shadow set holds no affine spheres: nfirst = 0)
+        for p, c in enumerate(order):
+            members = idx[c][idx[c] >= 0]
+            has_aff = bool(len(members)) and bool(np.any((members < ns) & aff[np.minimum(members, max(ns - 1, 0))]))
+            assert has_aff == (p < nfirst), (which, p, int(c))
+    nruns0 = (nfirst + 7) // 8
+    assert run.shape[0] == nruns0 + (ncl - nfirst + 7) // 8
+    c64 = cl.astype(np.float64)
+    r64 = run.astype(np.float64)
+    for p, c in enumerate(order):
+        r = p // 8 if p < nfirst else nruns0 + (p - nfirst) // 8
+        if not np.isfinite(c64[c, 3]):
+            assert r64[r, 3] == np.inf, (which, p)
+            continue
+        if r64[r, 3] == np.inf:
+            continue
+        reach = np.sqrt(((c64[c, :3] - r64[r, :3]) ** 2).sum()) + c64[c, 3]
+        assert reach <= r64[r, 3], (which, p, float(reach), float(r64[r, 3]))
+    return ncl
+
+
+@pytest.mark.parametrize("path", _scene_paths(), ids=os.path.basename)
+def test_run_spheres_of_the_test_scenes(path):
+    sc = rt.load_scene(path)
+    for which in (0, 1, 2):
+        _check_runs(sc, which)
+    sc.close()
+
+
+def test_per_ray_set_of_a_scene_of_several_segments():
+    """More than 16,384 primitives: the closest-hit set is cut into segments and the per-ray traversal walks a set of its own
+    (which = 2) -- every invariant on that one too, and it is not the segmented set."""
+    p = os.path.join(tempfile.gettempdir(), "rtx_clusters_big_%d.txt" % os.getpid())
+    rt.scenegen.write_c4(p, nspheres=9000, ntriangles=9000)
+    sc = rt.load_scene(p)
+    n2, slots2 = _check_set(sc, 2)
+    n0 = rt.cluster_records(sc, 0)[0].shape[0]
+    assert slots2 == 18000 and n2 <= n0
+    _check_runs(sc, 2)
+    _check_runs(sc, 0)
     sc.close()
     os.remove(p)
