@@ -488,7 +488,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             // a finer map for dense scenes, as the sort grid of the packet form takes (C5, 100,000 triangles: 78.5 / 56.6 / 47.0 ms
             // per frame with 256 / 512 / 1024 cells a side; C4, 10,000 primitives: 2.88 / 2.76 / 2.82)
             if (c->S.nsb >= 32768 && !ab_knob("RTX_CELL_G")) G0 = 1024;
-            constexpr size_t kMaxLists = (size_t)1 << 26;
+            constexpr size_t kMaxLists = (size_t)1 << 25;  // (one build wave per list: a launch holds fewer than 2^32 threads)
             while ((size_t)c->S.nl * G0 * G0 > kMaxLists && G0 > 8) G0 /= 2;
             // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);

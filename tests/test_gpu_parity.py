@@ -336,3 +336,31 @@ def test_camera_table_cases(rt, gpu, tmp_path, kind):
         assert same.all(), "%s %s: %d pixels differ" % (kind, extra, int((~same).sum()))
         assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
         assert sa.hits > 0 or extra
+
+
+def test_many_lights_take_a_coarser_map(rt, gpu, tmp_path):
+    """200 lights: one list per (light, cell) would pass what one build launch can hold at 512 cells a side, so the tables take
+    a coarser map (rtx_device.hip: kMaxLists).  Default kernels against the exact-only kernels, bit for bit."""
+    rng = np.random.default_rng(5)
+    rec = ["light %.3f %.3f %.3f 0.02 0.02 0.02" % (rng.uniform(-40, 40), rng.uniform(-10, 40), rng.uniform(-100, 10)) for _ in range(200)]
+    mat = "1 1 1  .8 .8 .8  .4 .4 .4"
+    for i in range(60):
+        c = rng.uniform(-20, 20, 3)
+        xf = i % 6 == 0
+        s = "sphere %.4f %.4f %.4f %.4f  %s  %s 1.3 %d 8" % (c[0], c[1], c[2] - 50, rng.uniform(1, 4), mat, "0.5 0" if i % 3 == 0 else "0 0", 1 if xf else 0)
+        if xf:
+            s += "  1.5 0 0  0 0.8 0  0 0 1.2  0 0 0"
+        rec.append(s)
+    for i in range(40):
+        v = rng.uniform(-20, 20, 3) + np.array([0, 0, -50])
+        e = rng.uniform(-8, 8, (2, 3))
+        rec.append("triangle %.4f %.4f %.4f  %.4f %.4f %.4f  %.4f %.4f %.4f  %s  0 0 1 8" % (v[0], v[1], v[2], *(v + e[0]), *(v + e[1]), mat))
+    p = tmp_path / "lights200.txt"
+    p.write_text("%d\n" % len(rec) + HEADER + "\n".join(rec) + "\n")
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(96, 54, 2))
+    b, sb = rt.render_f32(sc, rt.Params.make(96, 54, 2, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert sa.shadow_form == 1 and sa.rays_shadow == 200 * sa.hits
