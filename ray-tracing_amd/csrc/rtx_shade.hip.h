@@ -19,9 +19,50 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
     if (live && !hit) {  // :436-438: background, no ambient
         L.val[3 * i + 0] = 0.4f; L.val[3 * i + 1] = 0.4f; L.val[3 * i + 2] = 0.4f;
     }
-    __shared__ int sh_alloc[2 * (BLOCK / 64) + 1];
-    int node = block_alloc(hit, nnodes, sh_alloc);
+    // ONE allocation per workgroup for the node slot and both kinds of child (round 3; the node and the children were two
+    // allocations, seven barriers between them, each waiting on the slowest of the workgroup's waves): whether a hit spawns a
+    // reflection or a refraction ray is a property of the primitive's material alone, read here ahead of the geometry.
+    constexpr int nw = BLOCK / 64;
+    __shared__ int sh_alloc[3 * nw + 2];
     bool want_refl = false, want_refr = false;
+    if (hit && spawn) {  // depth < MAX_depth (:449)
+        const int prim0 = pw & ~kTFlag;
+        float refl0, tran0;
+        if (prim0 < S.ns) { refl0 = S.sph[prim0].reflectivity; tran0 = S.sph[prim0].transparency; }
+        else if (prim0 < S.ns + S.nt) { refl0 = S.tri[prim0 - S.ns].reflectivity; tran0 = S.tri[prim0 - S.ns].transparency; }
+        else { refl0 = S.poly[prim0 - S.ns - S.nt].reflectivity; tran0 = S.poly[prim0 - S.ns - S.nt].transparency; }
+        want_refl = refl0 > 0.0f;
+        want_refr = tran0 > 0.0f;
+    }
+    int node = -1, crefl = -1, crefr = -1;
+    {
+        const unsigned long long m0 = __ballot(hit), m1 = __ballot(want_refl), m2 = __ballot(want_refr);
+        const int w = threadIdx.x >> 6;
+        const int p0 = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
+        const int p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
+        const int p2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
+        if ((threadIdx.x & 63) == 0) { sh_alloc[w] = __popcll(m0); sh_alloc[nw + w] = __popcll(m1); sh_alloc[2 * nw + w] = __popcll(m2); }
+        __syncthreads();
+        int off0 = 0, off1 = 0, off2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;
+        for (int k = 0; k < nw; k++) {
+            if (k < w) { off0 += sh_alloc[k]; off1 += sh_alloc[nw + k]; off2 += sh_alloc[2 * nw + k]; }
+            tot0 += sh_alloc[k]; tot1 += sh_alloc[nw + k]; tot2 += sh_alloc[2 * nw + k];
+        }
+        if (threadIdx.x == 0) {  // (two atomics in flight together; slots the loop above does not read)
+            sh_alloc[3 * nw] = tot0 ? atomicAdd(nnodes, tot0) : 0;
+            sh_alloc[3 * nw + 1] = (tot1 + tot2) ? atomicAdd(nnext, tot1 + tot2) : 0;
+        }
+        __syncthreads();
+        const int base0 = sh_alloc[3 * nw], base1 = sh_alloc[3 * nw + 1];
+        if (hit) node = base0 + off0 + p0;
+        // reflection rays take the first slots of the workgroup's run, refraction rays the rest
+        if (want_refl) crefl = base1 + off1 + p1;
+        if (want_refr) crefr = base1 + tot1 + off2 + p2;
+        // never past the next level's capacity (measured at creation, rtx_device.hip: cannot happen for the frame the
+        // context was calibrated on): the child is dropped and counted, its colour term is then simply missing
+        if (want_refl && crefl >= N.cap) { want_refl = false; crefl = -1; atomicAdd(overflow, 1); }
+        if (want_refr && crefr >= N.cap) { want_refr = false; crefr = -1; atomicAdd(overflow, 1); }
+    }
     F3 o = f3(0, 0, 0), d = o, normal = o, ip = o, rd = o;
     float fres = 0.0f, fratio = 0.0f, eta = 1.0f;
     if (hit) {
@@ -74,9 +115,9 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
                     insphere = true;
                 }
             }
-            want_refl = reflectivity > 0.0f;
-            want_refr = transparency > 0.0f;
-            if (want_refl || want_refr) {
+            // (want_refl / want_refr: reflectivity > 0 / transparency > 0, decided before the allocation above; a child that found
+            // no room is dropped there)
+            if (reflectivity > 0.0f || transparency > 0.0f) {
                 fratio = -(dot3(rd, normal));
                 fres = fresnel_term(fratio);
                 eta = ri;
@@ -87,37 +128,6 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         L.n_nx[node] = normal.x; L.n_ny[node] = normal.y; L.n_nz[node] = normal.z;
         L.n_px[node] = ip.x; L.n_py[node] = ip.y; L.n_pz[node] = ip.z;
         L.n_fres[node] = fres;
-    }
-    if (!spawn) {
-        if (hit) { L.n_crefl[node] = -1; L.n_crefr[node] = -1; }
-        return;
-    }
-    // both kinds of child from ONE allocation per workgroup: reflection rays take the first slots of the
-    // workgroup's run, refraction rays the rest (two barriers instead of six)
-    int crefl = -1, crefr = -1;
-    {
-        const unsigned long long m1 = __ballot(want_refl), m2 = __ballot(want_refr);
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        constexpr int nw = BLOCK / 64;
-        const int p1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
-        const int p2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
-        if (lane == 0) { sh_alloc[w] = __popcll(m1); sh_alloc[nw + w] = __popcll(m2); }  // free: block_alloc ended with a barrier
-        __syncthreads();
-        int off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
-        for (int k = 0; k < nw; k++) {
-            if (k < w) { off1 += sh_alloc[k]; off2 += sh_alloc[nw + k]; }
-            tot1 += sh_alloc[k]; tot2 += sh_alloc[nw + k];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) sh_alloc[2 * nw] = (tot1 + tot2) ? atomicAdd(nnext, tot1 + tot2) : 0;
-        __syncthreads();
-        const int base = sh_alloc[2 * nw];
-        if (want_refl) crefl = base + off1 + p1;
-        if (want_refr) crefr = base + tot1 + off2 + p2;
-        // never past the next level's capacity (measured at creation, rtx_device.hip: cannot happen for the frame the
-        // context was calibrated on): the child is dropped and counted, its colour term is then simply missing
-        if (want_refl && crefl >= N.cap) { want_refl = false; crefl = -1; atomicAdd(overflow, 1); }
-        if (want_refr && crefr >= N.cap) { want_refr = false; crefr = -1; atomicAdd(overflow, 1); }
     }
     if (hit) { L.n_crefl[node] = crefl; L.n_crefr[node] = crefr; }
     if (want_refl) {  // :464-468
