@@ -364,3 +364,35 @@ def test_many_lights_take_a_coarser_map(rt, gpu, tmp_path):
     assert same.all(), "%d pixels differ" % int((~same).sum())
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
     assert sa.shadow_form == 1 and sa.rays_shadow == 200 * sa.hits
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cameras_culled_equals_exact(rt, gpu, tmp_path, seed):
+    """Random scenes under random cameras (inside or outside the cloud, any view direction, an up vector not orthogonal to it,
+    fields of view from a few degrees to more than 150 -- tools/dbg/fuzz_camera.py runs more seeds): the primary rays' table
+    and everything behind it against the exact-only kernels, bit for bit."""
+    rng = np.random.default_rng(5000 + seed)
+    ns, nt, nl = int(rng.integers(50, 2500)), int(rng.integers(0, 2500)), int(rng.integers(1, 4))
+    lights = [(float(rng.uniform(-45, 45)), float(rng.uniform(-30, 45)), float(rng.uniform(-130, 20)), 0.3, 0.3, 0.3) for _ in range(nl)]
+    p = tmp_path / ("fuzzcam_%d.txt" % seed)
+    rt.scenegen.write_scene(str(p), ns, nt, lights, seed=3000 + seed, frac_affine=float(rng.uniform(0, 0.5)),
+                            frac_reflective=float(rng.uniform(0.1, 0.8)), frac_refractive=float(rng.uniform(0, 0.3)),
+                            affine="general" if seed % 2 else "diag", radius=(0.2, float(rng.uniform(0.5, 5.0))),
+                            edge=float(rng.uniform(0.5, 10.0)))
+    cam = rng.uniform(-1, 1, 3) * float(rng.choice([0.1, 0.5, 1.0, 4.0]))
+    if abs(cam[2]) < 0.05:
+        cam[2] = 0.3
+    vrp = np.array([rng.uniform(-45, 45), rng.uniform(-30, 30), rng.uniform(-130, 10)]) if seed % 3 else np.zeros(3)
+    vpn = rng.normal(size=3); vpn /= np.linalg.norm(vpn)
+    up = rng.normal(size=3); up /= np.linalg.norm(up)
+    repl = {"camera": "camera %.5f %.5f %.5f" % tuple(cam), "vrp": "vrp %.4f %.4f %.4f" % tuple(vrp),
+            "vpn": "vpn %.6f %.6f %.6f" % tuple(vpn), "up": "up %.6f %.6f %.6f" % tuple(up)}
+    lines = [repl.get(l.split()[0], l) if l.split() else l for l in p.read_text().splitlines()]
+    p.write_text("\n".join(lines) + "\n")
+    sc = rt.load_scene(str(p))
+    md = int(rng.integers(1, 5))
+    a, sa = rt.render_f32(sc, rt.Params.make(400, 225, md))
+    b, sb = rt.render_f32(sc, rt.Params.make(400, 225, md, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
