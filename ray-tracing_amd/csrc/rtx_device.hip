@@ -169,6 +169,7 @@ struct rtx_context {
     // (the library's static scratch array) instead of hipMalloc; nothing is created or freed on the device.
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    unsigned long long* d_cursor = nullptr; // the table builds' cursor (build_cell_table)
     int* d_overflow = nullptr;              // rays k_setup could not place (a level's capacity exceeded): 0 by construction
     bool calibrated = false;                // level capacities come from the calibration pass (fan-out 2 scenes)
     bool serial = false;                    // RTX_F_SERIAL / arena mode: everything on the caller's stream, no side streams, no fork/join events
@@ -254,6 +255,68 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
 
 static int calibrate_counts(rtx_context* c, int* d_blk);
 static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out);
+
+// One direction-cell table (rtx_cells.hip.h), built in ONE pass: a build workgroup takes its cells' range of the table with an
+// atomic add on a cursor, so the table is allocated for a GUESS of its size and built again at the size the cursor reports if the
+// guess was short; a table beyond the budget takes a coarser map (a quarter of the cells), as does one the device has no room
+// for.  kind 0: plain shadow casters per (light, cell), entries { primitive, dneed }; 1: affine spheres per (light, cell, slab),
+// entries = record indices; 2: every primitive per camera cell.  off == nullptr on return: no map is coarse enough, no table.
+struct TableSpec {
+    int kind, napex, G0, Gmin;
+    size_t max_lists;
+    uint64_t guess, max_entries;
+    const float* d_range;
+    int tight;
+    CamCells cam;
+};
+struct TableOut { const int2* off = nullptr; const void* ent = nullptr; int G = 0, attempt = 0; uint64_t entries = 0, lists = 0, room = 0; };
+
+static int build_cell_table(rtx_context* c, const TableSpec& T, TableOut* out)
+{
+    *out = TableOut{};
+    int rc = RTX_OK;
+    if (!c->d_cursor && (rc = c->dalloc(&c->d_cursor, 1))) return rc;
+    const int mult = T.kind == 1 ? kAffSlabs : 1;
+    const size_t esz = T.kind == 1 ? sizeof(int) : sizeof(int2);
+    for (int G = T.G0; G >= T.Gmin; G /= 2) {
+        if ((size_t)T.napex * G * G * mult > T.max_lists) continue;
+        const int nwave = T.napex * G * G;       // one build wave per (apex, cell)
+        const int ncell = nwave * mult;          // lists
+        uint64_t want = std::min<uint64_t>(std::max<uint64_t>(T.guess, (uint64_t)1 << 16), T.max_entries);
+        int2* off = nullptr;
+        if ((rc = c->dalloc(&off, (size_t)ncell))) return rc;
+        bool coarser = false;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            char* ent = nullptr;
+            rc = c->dalloc(&ent, ((size_t)want + kCellPad) * esz);
+            if (rc == RTX_E_OOM) { (void)hipGetLastError(); coarser = true; break; }  // no room for this map: a coarser one
+            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(c->d_cursor, 0, sizeof(unsigned long long), nullptr));
+            if (T.kind == 1) hipLaunchKernelGGL(k_aff_build, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, T.d_range, off, reinterpret_cast<int*>(ent), c->d_cursor, (unsigned long long)want);
+            else hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(nwave / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, T.d_range, off, reinterpret_cast<int2*>(ent),
+                                    c->d_cursor, (unsigned long long)want, T.tight, T.cam);
+            HIPCHK(hipGetLastError());
+            unsigned long long sum = 0;
+            HIPCHK(hipMemcpy(&sum, c->d_cursor, sizeof sum, hipMemcpyDeviceToHost));  // (waits for the build)
+            if (sum <= want) {
+                // the walks read a few entries past a list's end: { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
+                HIPCHK(hipMemset(ent + (size_t)sum * esz, T.kind == 1 ? 0 : 0xff, esz * kCellPad));
+                out->off = off; out->ent = ent; out->G = G; out->attempt = attempt; out->entries = sum; out->lists = (uint64_t)ncell; out->room = want;
+                return RTX_OK;
+            }
+            // short: give the entries back (the last allocation) and build again at the size it needs, or coarser
+            (void)hipFree(c->allocs.back());
+            c->allocs.pop_back();
+            if (sum > T.max_entries || attempt == 1) { coarser = true; break; }
+            want = sum;
+        }
+        if (coarser) {
+            (void)hipFree(c->allocs.back());  // the offsets of this map
+            c->allocs.pop_back();
+        }
+    }
+    return RTX_OK;
+}
 
 static int context_create_impl(const rtx_scene* scene, const rtx_params* params, rtx_context* c)
 {
@@ -493,79 +556,33 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             // entries a table may hold: 2^31 by its int offsets, an eighth of the workspace budget by size (8 B each)
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
-            unsigned long long* d_cursor = nullptr;
-            HIPCHK(hipMalloc((void**)&d_cursor, sizeof(unsigned long long)));
             int cells_tight = 1;  // entries by what the exact tests can accept (rtx_cells.hip.h); 0: by what the per-ray filter can pass
             if (const char* e = ab_knob("RTX_CELL_TIGHT")) cells_tight = std::atoi(e) ? 1 : 0;
-            // One pass per table (rtx_cells.hip.h: a wave takes its cell's range with an atomic add on a cursor): the table is
-            // allocated for a GUESS of its size -- 128 entries per caster and light for the plain table (C4 has 60, C5 85), 16,384 per
-            // affine sphere and light (C4: 14,150) -- and built again at the size the cursor reports if the guess was short; a table
-            // beyond the budget takes a coarser map (a quarter of the cells), as does one the device has no room for.  The plain table
-            // has one list of { primitive, dneed } per (light, cell); the affine table one list of record indices per (light, cell, slab).
+            // the guesses: 128 entries per caster and light for the plain table (C4 has 60, C5 85), 16,384 per affine sphere and
+            // light (C4: 14,150).  (The affine lists gain nothing from cells finer than 256 a side -- what they list is set by the slabs
+            // of origin distance, 13.8 M filter tests per C4 frame either way -- and 33 M lists take 29 ms to build against 6.)
             uint64_t tab_entries[2] = {0, 0}, tab_lists[2] = {0, 0};
-            auto build = [&](const bool affine, const int2** off_out, const void** ent_out, int* G_out) -> int {
-                const int mult = affine ? kAffSlabs : 1;
-                const size_t esz = affine ? sizeof(int) : sizeof(int2);
-                for (int G = G0; G >= 8; G /= 2) {
-                    // (the affine lists gain nothing from cells finer than 256 a side -- what they list is set by the slabs of origin
-                    // distance, 13.8 M filter tests per C4 frame either way -- and 33 M lists take 29 ms to build against 6)
-                    if ((size_t)c->S.nl * G * G * mult > (affine ? ((size_t)1 << 24) : kMaxLists)) continue;
-                    const int nwave = c->S.nl * G * G;       // one build wave per (light, cell)
-                    const int ncell = nwave * mult;          // lists
-                    uint64_t want = (uint64_t)c->S.nl * (affine ? (uint64_t)c->S.naff * 16384 : (uint64_t)c->S.nsb * 128);
-                    want = std::min<uint64_t>(std::max<uint64_t>(want, 1 << 16), max_entries);
-                    int2* off = nullptr;
-                    int r = c->dalloc(&off, (size_t)ncell);
-                    if (r) return r;
-                    bool coarser = false;
-                    for (int attempt = 0; attempt < 2; attempt++) {
-                        char* ent = nullptr;
-                        r = c->dalloc(&ent, ((size_t)want + kCellPad) * esz);
-                        if (r == RTX_E_OOM) { (void)hipGetLastError(); coarser = true; break; }  // no room for this map: a coarser one
-                        if (r) return r;
-                        HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), nullptr));
-                        if (affine) hipLaunchKernelGGL(k_aff_build, dim3((unsigned)nwave), dim3(64), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int*>(ent), d_cursor, (unsigned long long)want);
-                        else hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(nwave / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dc, off, reinterpret_cast<int2*>(ent), d_cursor, (unsigned long long)want, cells_tight, CamCells{});
-                        HIPCHK(hipGetLastError());
-                        unsigned long long sum = 0;
-                        HIPCHK(hipMemcpy(&sum, d_cursor, sizeof sum, hipMemcpyDeviceToHost));  // (waits for the build)
-                        if (sum <= want) {
-                            // the walks read a few entries past a list's end: plain { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
-                            HIPCHK(hipMemset(ent + (size_t)sum * esz, affine ? 0 : 0xff, esz * kCellPad));
-                            *off_out = off; *ent_out = ent; *G_out = G;
-                            tab_entries[affine ? 1 : 0] = sum; tab_lists[affine ? 1 : 0] = (uint64_t)ncell;
-                            if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: %s table G = %d, %d lists, %llu entries (room for %llu, attempt %d)\n", affine ? "affine" : "plain", G, ncell, sum, (unsigned long long)want, attempt);
-                            return RTX_OK;
-                        }
-                        // short: give the entries back (the last allocation) and build again at the size it needs, or coarser
-                        (void)hipFree(c->allocs.back());
-                        c->allocs.pop_back();
-                        if (sum > max_entries || attempt == 1) { coarser = true; break; }
-                        want = sum;
-                    }
-                    if (coarser) {
-                        (void)hipFree(c->allocs.back());  // the offsets of this map
-                        c->allocs.pop_back();
-                        continue;
-                    }
-                }
-                return RTX_OK;  // no map is coarse enough: no table
-            };
+            const bool verbose_tab = ab_knob("RTX_VERBOSE") != nullptr;
+            if (!c->d_cursor && (rc = c->dalloc(&c->d_cursor, 1))) return rc;  // (ahead of tab_mark: the camera's table uses it too)
             const size_t tab_mark = c->allocs.size();
             {
-                const void* e = nullptr;
-                rc = build(false, &c->cells.off, &e, &c->cells.G);
-                c->cells.ent = static_cast<const int2*>(e);
+                TableOut to;
+                TableSpec ts{0, c->S.nl, G0, 8, kMaxLists, (uint64_t)c->S.nl * (uint64_t)c->S.nsb * 128, max_entries, d_dc, cells_tight, CamCells{}};
+                rc = build_cell_table(c, ts, &to);
+                c->cells.off = to.off; c->cells.ent = static_cast<const int2*>(to.ent); c->cells.G = to.G;
+                tab_entries[0] = to.entries; tab_lists[0] = to.lists;
+                if (verbose_tab && to.off) std::fprintf(stderr, "rtx: plain table G = %d, %llu lists, %llu entries (room for %llu, attempt %d)\n", to.G, (unsigned long long)to.lists, (unsigned long long)to.entries, (unsigned long long)to.room, to.attempt);
                 phase("plain table");
                 // (without the plain table the packet kernels trace everything, with their own affine stage)
                 if (!rc && c->cells.off && c->S.naff > 0) {
-                    e = nullptr;
-                    rc = build(true, &c->cells.aoff, &e, &c->cells.aG);
-                    c->cells.aent = static_cast<const int*>(e);
+                    ts.kind = 1; ts.max_lists = (size_t)1 << 24; ts.guess = (uint64_t)c->S.nl * (uint64_t)c->S.naff * 16384;
+                    rc = build_cell_table(c, ts, &to);
+                    c->cells.aoff = to.off; c->cells.aent = static_cast<const int*>(to.ent); c->cells.aG = to.G;
+                    tab_entries[1] = to.entries; tab_lists[1] = to.lists;
+                    if (verbose_tab && to.off) std::fprintf(stderr, "rtx: affine table G = %d, %llu lists, %llu entries (room for %llu, attempt %d)\n", to.G, (unsigned long long)to.lists, (unsigned long long)to.entries, (unsigned long long)to.room, to.attempt);
                     phase("affine table");
                 }
             }
-            (void)hipFree(d_cursor);
             if (rc) return rc;
             c->cells.dmax = d_dc;
             // tight entries go straight to the exact stages: the per-ray filter in front of them rejected one pair in five and cost
@@ -677,43 +694,15 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             const uint64_t wbytes = params->workspace_bytes ? params->workspace_bytes : ((uint64_t)32 << 30);
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
             const uint64_t nprim_all = (uint64_t)P.bounds.size();
-            unsigned long long* d_cursor = nullptr;
-            if (apex_ok) HIPCHK(hipMalloc((void**)&d_cursor, sizeof(unsigned long long)));
-            for (int G = Gc; apex_ok && G >= 64 && !c->cam.off; G /= 2) {
-                const int ncell = G * G;
-                uint64_t want = std::min<uint64_t>(std::max<uint64_t>(nprim_all * 256, (uint64_t)1 << 20), max_entries);
-                int2* off = nullptr;
-                int r = c->dalloc(&off, (size_t)ncell);
-                if (r) { (void)hipFree(d_cursor); return r; }
-                bool coarser = false;
-                for (int attempt = 0; attempt < 2; attempt++) {
-                    int2* ent = nullptr;
-                    r = c->dalloc(&ent, (size_t)want + kCellPad);
-                    if (r == RTX_E_OOM) { (void)hipGetLastError(); coarser = true; break; }
-                    if (r) { (void)hipFree(d_cursor); return r; }
-                    HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), nullptr));
-                    hipLaunchKernelGGL(k_cells_build, dim3((unsigned)(ncell / kCellsPerGroup)), dim3(64 * kCellsPerGroup), 0, 0, c->S, G, d_dcam, off, ent, d_cursor,
-                                       (unsigned long long)want, 1, cm);
-                    HIPCHK(hipGetLastError());
-                    unsigned long long sum = 0;
-                    HIPCHK(hipMemcpy(&sum, d_cursor, sizeof sum, hipMemcpyDeviceToHost));
-                    if (sum <= want) {
-                        HIPCHK(hipMemset(ent + sum, 0xff, sizeof(int2) * kCellPad));
-                        c->cam.off = off; c->cam.ent = ent; c->cam.G = G; c->cam.apex = cm.apex;
-                        if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: camera table G = %d, %llu entries (room for %llu, attempt %d), view cone cos %.4f\n", G, sum, (unsigned long long)want, attempt, cosv);
-                        break;
-                    }
-                    (void)hipFree(c->allocs.back());
-                    c->allocs.pop_back();
-                    if (sum > max_entries || attempt == 1) { coarser = true; break; }
-                    want = sum;
-                }
-                if (coarser) {
-                    (void)hipFree(c->allocs.back());
-                    c->allocs.pop_back();
+            if (apex_ok) {
+                TableOut to;
+                const TableSpec ts{2, 1, Gc, 64, (size_t)1 << 25, nprim_all * 256, max_entries, d_dcam, 1, cm};
+                if ((rc = build_cell_table(c, ts, &to))) return rc;
+                if (to.off) {
+                    c->cam.off = to.off; c->cam.ent = static_cast<const int2*>(to.ent); c->cam.G = to.G; c->cam.apex = cm.apex;
+                    if (ab_knob("RTX_VERBOSE")) std::fprintf(stderr, "rtx: camera table G = %d, %llu entries (room for %llu, attempt %d), view cone cos %.4f\n", to.G, (unsigned long long)to.entries, (unsigned long long)to.room, to.attempt, cosv);
                 }
             }
-            if (d_cursor) (void)hipFree(d_cursor);
             phase("camera table");
         }
     }
