@@ -318,11 +318,12 @@ __global__ __launch_bounds__(kBlock) void k_aa_quantise4(const float* fimg, cons
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) win[dy][k + 1][ch] = m[k * 3 + ch];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            win[dy][0][ch] = (x0 > 0) ? p[-3 + ch] : 0.0f;
-            win[dy][5][ch] = (x0 + 4 < width) ? p[12 + ch] : 0.0f;
-        }
+        // the pixel on either side: one aligned 16-byte load each (p is 48-byte aligned), not three dwords
+        float4 lft = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rgt = lft;
+        if (x0 > 0) lft = *reinterpret_cast<const float4*>(p - 4);
+        if (x0 + 4 < width) rgt = *reinterpret_cast<const float4*>(p + 12);
+        win[dy][0][0] = lft.y; win[dy][0][1] = lft.z; win[dy][0][2] = lft.w;
+        win[dy][5][0] = rgt.x; win[dy][5][1] = rgt.y; win[dy][5][2] = rgt.z;
     }
     unsigned char bytes[12];
 #pragma unroll
