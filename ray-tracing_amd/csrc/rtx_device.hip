@@ -406,6 +406,11 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             c->S.poly = pg; c->S.poly_verts = reinterpret_cast<const float4*>(pv); c->S.np = (int)P.poly.size();  // + planes, if traced
             c->S.mt = (params->flags & RTX_F_TRI_MOLLER_TRUMBORE) ? 1 : 0;
         }
+        {
+            float* m4 = nullptr;
+            if ((rc = c->upload(&m4, P.mat4))) return rc;
+            c->S.mat4 = reinterpret_cast<const float4*>(m4);
+        }
         c->S.ns = (int)P.sph.size(); c->S.nt = (int)P.tri.size(); c->S.nl = (int)P.lights.size();
         c->S.ambient = {P.ambient.x, P.ambient.y, P.ambient.z};
         static_assert(sizeof(BoundSphere) == sizeof(float4), "filter record is one float4");

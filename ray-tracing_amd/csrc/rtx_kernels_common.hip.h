@@ -19,6 +19,7 @@ struct SceneDev {
     int np;                       // polygons: primitive index ns + nt + i, traced after the triangles (:421-434); with
                                   // RTX_F_TRACE_PLANES the planes follow them as records with vertex count -1
     const rtx_polygon* poly;      // [np] raw records (materials)
+    const float4* mat4;           // [(ns + nt + np) * 4] packed materials (rtx_pack.h: mat4): what set-up and shading read per hit
     const float4* poly_verts;     // vertices, x y z 0; a polygon's run starts at its hot record's first_vertex
     const float4* sph_hot;        // [ns]  cx cy cz r^2
     const int* sph_xf;            // [ns]

@@ -391,6 +391,16 @@ void pack_scene(const rtx_scene& sc, int width, int height, PackedScene& P, uint
         if (f > P.max_fanout) P.max_fanout = f;
     }
 
+    {   // packed materials, in primitive order: spheres, triangles, polygons (+ planes)
+        auto put = [&](float refl, float tran, float ri, float radius, const rtx_vec3& col, float expo, const rtx_vec3& spec, float xf, const rtx_vec3& dif) {
+            const float r[16] = {refl, tran, ri, radius, col.x, col.y, col.z, expo, spec.x, spec.y, spec.z, xf, dif.x, dif.y, dif.z, 0.0f};
+            P.mat4.insert(P.mat4.end(), r, r + 16);
+        };
+        for (const rtx_sphere& q : P.sph) put(q.reflectivity, q.transparency, q.refractive_index, q.radius, q.color, q.specexpo, q.speccoeff, q.istransformed ? 1.0f : 0.0f, q.diffcolor);
+        for (const rtx_triangle& q : P.tri) put(q.reflectivity, q.transparency, q.refractive_index, 0.0f, q.color, q.specexpo, q.speccoeff, 0.0f, q.diffcolor);
+        for (const rtx_polygon& q : P.poly) put(q.reflectivity, q.transparency, q.refractive_index, 0.0f, q.color, q.specexpo, q.speccoeff, 0.0f, q.diffcolor);
+    }
+
     // filter records.  guard = 16 x the extent of everything finite in the scene.
     double ext = 1.0;
     auto grow = [&](double v) { if (std::isfinite(v) && std::fabs(v) < 1e30 && std::fabs(v) > ext) ext = std::fabs(v); };

@@ -108,6 +108,11 @@ struct PackedScene {
     // independent 16-byte loads: sphere { c, r*r | im.a, im.b.x | im.b.yz, im.c.xy | im.c.z, im.d | xf, 0, 0, 0 },
     // triangle = its TriHot
     std::vector<TriHot>      prim_hot;
+    // materials packed for the set-up and shading kernels (round 3: they gathered a dozen scalars out of the 120- / 88- / 84-byte
+    // AoS records per hit -- one cache lookup per lane and scalar), four floats a row, copies of the records' own binary32 fields:
+    //   mat4[k * 4 + 0] = { reflectivity, transparency, refractive_index, radius (spheres; 0 otherwise) }
+    //   mat4[k * 4 + 1] = { color.xyz, specexpo }   [+ 2] = { speccoeff.xyz, istransformed }   [+ 3] = { diffcolor.xyz, 0 }
+    std::vector<float>       mat4;       // [(nspheres + ntriangles + npolygons (+ planes)) * 16]
     std::vector<rtx_triangle> tri;
     std::vector<rtx_light>   lights;
     // polygons (raytracing.cpp:71-80, :289-325): raw records for the materials, vertices as float4 (x y z 0);

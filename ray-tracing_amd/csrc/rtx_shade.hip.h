@@ -26,13 +26,9 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
     __shared__ int sh_alloc[3 * nw + 2];
     bool want_refl = false, want_refr = false;
     if (hit && spawn) {  // depth < MAX_depth (:449)
-        const int prim0 = pw & ~kTFlag;
-        float refl0, tran0;
-        if (prim0 < S.ns) { refl0 = S.sph[prim0].reflectivity; tran0 = S.sph[prim0].transparency; }
-        else if (prim0 < S.ns + S.nt) { refl0 = S.tri[prim0 - S.ns].reflectivity; tran0 = S.tri[prim0 - S.ns].transparency; }
-        else { refl0 = S.poly[prim0 - S.ns - S.nt].reflectivity; tran0 = S.poly[prim0 - S.ns - S.nt].transparency; }
-        want_refl = refl0 > 0.0f;
-        want_refr = tran0 > 0.0f;
+        const float4 m0 = S.mat4[(size_t)(pw & ~kTFlag) * 4];  // { reflectivity, transparency, refractive index, radius }
+        want_refl = m0.x > 0.0f;
+        want_refr = m0.y > 0.0f;
     }
     int node = -1, crefl = -1, crefr = -1;
     {
@@ -72,24 +68,22 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         bool tflag = (pw & kTFlag) != 0;
         int prim = pw & ~kTFlag;
         bool is_sphere = prim < S.ns;
-        float reflectivity, transparency, ri;
+        const float4 m0 = S.mat4[(size_t)prim * 4];  // { reflectivity, transparency, refractive index, radius }: the records' own floats
+        const float reflectivity = m0.x, transparency = m0.y, ri = m0.z;
         if (is_sphere) {
-            const rtx_sphere& s = S.sph[prim];
-            const rtx_xmatrix& im = S.sph_im[prim];
+            const float4 sh = S.sph_hot[prim];  // { centre, r * r }
+            const bool sxf = S.sph_xf[prim] != 0;
             // recompute the winner's object-space normal (:229-231, :395-398)
             F3 to = o, td = d;
-            if (s.istransformed) { to = inv_apply(o, im); td = inv_apply(d, im); }
+            if (sxf) { const rtx_xmatrix& im = S.sph_im[prim]; to = inv_apply(o, im); td = inv_apply(d, im); }
             td = normalized(td);
-            normal = sphere_normal(to, td, nearest, s);
-            if (s.istransformed) normal = inv_apply_normal(normal, im);
-            reflectivity = s.reflectivity; transparency = s.transparency; ri = s.refractive_index;
+            normal = f3((to.x + td.x * nearest - sh.x) / m0.w, (to.y + td.y * nearest - sh.y) / m0.w, (to.z + td.z * nearest - sh.z) / m0.w);  // sphere_normal
+            if (sxf) normal = inv_apply_normal(normal, S.sph_im[prim]);
         } else if (prim < S.ns + S.nt) {
             const float4* p = S.tri_hot + (size_t)(prim - S.ns) * 5;
             float4 q0 = p[0];
             float vd = q0.x * d.x + q0.y * d.y + q0.z * d.z;
             normal = (vd > 0.0f) ? f3(-q0.x, -q0.y, -q0.z) : f3(q0.x, q0.y, q0.z);  // :343-347
-            const rtx_triangle& t = S.tri[prim - S.ns];
-            reflectivity = t.reflectivity; transparency = t.transparency; ri = t.refractive_index;
         } else {
             const float4 q0 = S.phot[(size_t)prim * 5];
             normal = f3(q0.x, q0.y, q0.z);  // :311: the stored normal, negated
@@ -98,8 +92,6 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
                 const float vd = q0.x * d.x + q0.y * d.y + q0.z * d.z;
                 if (vd > 0.0f) normal = f3(-q0.x, -q0.y, -q0.z);
             }
-            const rtx_polygon& g = S.poly[prim - S.ns - S.nt];
-            reflectivity = g.reflectivity; transparency = g.transparency; ri = g.refractive_index;
         }
         ip = f3(o.x + nearest * d.x, o.y + nearest * d.y, o.z + nearest * d.z);  // :440
         if (tflag) ip = fwd_apply(ip, S.sph[prim].mat);                          // :441-444
@@ -201,23 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_unwind(SceneDev S, LevelDev L, Level
     F3 d = f3(L.dx[i], L.dy[i], L.dz[i]);
     F3 n = f3(L.n_nx[j], L.n_ny[j], L.n_nz[j]);
     F3 ip = f3(L.n_px[j], L.n_py[j], L.n_pz[j]);
-    F3 color, spec, diff;
-    float transparency, specexpo;
-    bool xf = false;
-    if (is_sphere) {
-        const rtx_sphere& s = S.sph[prim];
-        color = f3(s.color); spec = f3(s.speccoeff); diff = f3(s.diffcolor);
-        transparency = s.transparency; specexpo = s.specexpo;
-        xf = s.istransformed != 0;
-    } else if (prim < S.ns + S.nt) {
-        const rtx_triangle& t = S.tri[prim - S.ns];
-        color = f3(t.color); spec = f3(t.speccoeff); diff = f3(t.diffcolor);
-        transparency = t.transparency; specexpo = t.specexpo;
-    } else {  // :527-556, :627-639: the triangle forms with the polygon's material
-        const rtx_polygon& g = S.poly[prim - S.ns - S.nt];
-        color = f3(g.color); spec = f3(g.speccoeff); diff = f3(g.diffcolor);
-        transparency = g.transparency; specexpo = g.specexpo;
-    }
+    // the material, packed (rtx_pack.h: mat4; polygons take the triangle forms with their own material, :527-556, :627-639)
+    const float4 m0 = S.mat4[(size_t)prim * 4], m1 = S.mat4[(size_t)prim * 4 + 1], m2 = S.mat4[(size_t)prim * 4 + 2], m3 = S.mat4[(size_t)prim * 4 + 3];
+    const F3 color = f3(m1.x, m1.y, m1.z), spec = f3(m2.x, m2.y, m2.z), diff = f3(m3.x, m3.y, m3.z);
+    const float transparency = m0.y, specexpo = m1.w;
+    const bool xf = is_sphere && m2.w != 0.0f;
     F3 pix = f3(0.0f, 0.0f, 0.0f);
     float fres = L.n_fres[j];
     int crefl = L.n_crefl[j], crefr = L.n_crefr[j];
