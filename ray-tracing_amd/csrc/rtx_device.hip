@@ -99,7 +99,8 @@ struct rtx_context {
     int* d_trace_rows = nullptr; int* d_row2ti = nullptr; int* d_own_rows = nullptr;
     float* d_fimg = nullptr;
     unsigned char* d_rgb8 = nullptr;
-    int* d_cnt = nullptr;                   // [2*levels]: rays per level, then nodes per level
+    int* d_cnt = nullptr;                   // [2*levels + 2]: rays of level k at [2k + 1], nodes of level k at [2k + 2] -- nodes(k) and rays(k + 1)
+                                            // are one aligned 64-bit word: k_setup takes both with ONE atomic per workgroup
     unsigned long long* d_totals = nullptr; // [2*levels]
     unsigned long long* d_tests = nullptr;  // [8] closest kinds, shadow kinds (RTX_F_COUNT_TESTS)
     int binG = 256, nbins = 0;              // light-space bins: nl * G * G
@@ -253,6 +254,8 @@ static int validate(const rtx_scene* sc, const rtx_params* p)
     return RTX_OK;
 }
 
+// the counters of generation k (rtx_context::d_cnt): `rays + k`, `nodes + k` as the launch sites write them
+struct CntPtr { int* p; int* operator+(int k) const { return p + 2 * k; } };
 static int calibrate_counts(rtx_context* c, int* d_blk);
 static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out);
 
@@ -716,7 +719,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
     if ((rc = c->upload(&c->d_own_rows, c->own_rows))) return rc;
     if ((rc = c->dalloc(&c->d_fimg, (size_t)ntrace * W * 3))) return rc;
     if ((rc = c->dalloc(&c->d_rgb8, (size_t)nown * W * 3))) return rc;
-    if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels))) return rc;
+    if ((rc = c->dalloc(&c->d_cnt, (size_t)2 * levels + 2))) return rc;
     // frame totals, test counters and packet statistics in one block: one memset per frame
     if ((rc = c->dalloc(&c->d_totals, (size_t)2 * levels + 16 + 3 * EX_KINDS))) return rc;
     c->d_tests = c->d_totals + 2 * levels;
@@ -1033,13 +1036,12 @@ static int calibrate_counts(rtx_context* c, int* d_blk)
 {
     const int W = c->width, levels = c->levels, ntrace = (int)c->trace_rows.size();
     hipStream_t st = nullptr;
-    int* rays = c->d_cnt;
-    int* nodes = c->d_cnt + levels;
+    const CntPtr rays{c->d_cnt + 1}, nodes{c->d_cnt + 2};
     int blk = 0;
     for (int ti0 = 0; ti0 < ntrace; ti0 += c->chunk_rows, blk++) {
         const int nrows = std::min(c->chunk_rows, ntrace - ti0);
         const size_t npix = (size_t)nrows * W;
-        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * 2 * levels, st));
+        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * (2 * (size_t)levels + 2), st));
         LevelDev L0 = c->L[0];
         L0.val = c->d_fimg + (size_t)ti0 * W * 3;
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
@@ -1053,10 +1055,10 @@ static int calibrate_counts(rtx_context* c, int* d_blk)
             if (k > 0) hipLaunchKernelGGL(k_closest_lanes<false>, dim3(std::max(g, grid_lanes_thin(live_cap, c->lanes16, c->lanes4))), dim3(kBlock), 0, st, c->lanes_scene(), Lk, rays + k, c->lanes16, c->lanes4);
             else if (live_cap < kPrefetchRays) hipLaunchKernelGGL((k_closest_f<true, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
             else hipLaunchKernelGGL((k_closest_f<false, false>), dim3(grid_for_isect(live_cap)), dim3(kBlock), 0, st, c->S, Lk, rays + k);
-            hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, rays + k + 1, spawn, c->d_overflow);
+            hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, spawn, c->d_overflow);
             live_cap = std::min(live_cap * 2, (size_t)c->L[k + 1].cap);
         }
-        HIPCHK(hipMemcpyAsync(d_blk + (size_t)blk * levels, rays, sizeof(int) * levels, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(d_blk + (size_t)blk * levels, sizeof(int), rays + 0, 2 * sizeof(int), sizeof(int), (size_t)levels, hipMemcpyDeviceToDevice, st));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
@@ -1083,9 +1085,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
     for (int ti0 = 0; ti0 < ntrace; ti0 += c->chunk_rows, nchunks++) {
         int nrows = std::min(c->chunk_rows, ntrace - ti0);
         size_t npix = (size_t)nrows * W;
-        int* rays = c->d_cnt;
-        int* nodes = c->d_cnt + levels;
-        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * 2 * levels, st));
+        const CntPtr rays{c->d_cnt + 1}, nodes{c->d_cnt + 2};
+        HIPCHK(hipMemsetAsync(c->d_cnt, 0, sizeof(int) * (2 * (size_t)levels + 2), st));
         LevelDev L0 = c->L[0];
         L0.val = c->d_fimg + (size_t)ti0 * W * 3;
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix)), dim3(kBlock), 0, st, L0, c->C, c->d_trace_rows, ti0, nrows, W, rays + 0);
@@ -1121,10 +1122,8 @@ static int context_render_impl(rtx_context* c, hipStream_t st, uint8_t* d_out)
             // generation 0 runs alone and every workgroup allocates: 1024-thread workgroups quarter its same-address
             // atomics; later generations share the chip with the shadow passes, where a 1024-thread workgroup waits
             // for a whole CU to drain
-            if (k == 0) hipLaunchKernelGGL(k_setup<kSetupBlock>, dim3((unsigned)((live_cap + kSetupBlock - 1) / kSetupBlock)), dim3(kSetupBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
-                               spawn ? rays + k + 1 : rays + k, spawn, c->d_overflow);
-            else hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k,
-                               spawn ? rays + k + 1 : rays + k, spawn, c->d_overflow);
+            if (k == 0) hipLaunchKernelGGL(k_setup<kSetupBlock>, dim3((unsigned)((live_cap + kSetupBlock - 1) / kSetupBlock)), dim3(kSetupBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, spawn, c->d_overflow);
+            else hipLaunchKernelGGL(k_setup<kBlock>, dim3(g), dim3(kBlock), 0, st, c->S, Lk, Ln, rays + k, nodes + k, spawn, c->d_overflow);
             if (c->S.nl > 0 && (count || exact_only)) {
                 if (timek) { HIPCHK(hipEventRecord(c->kev[kev_used], st)); }
                 if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(g, c->S.nl), dim3(kBlock), 0, st, c->S, Lk, nodes + k, c->d_tests + 4);

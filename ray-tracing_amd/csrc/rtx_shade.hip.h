@@ -10,7 +10,7 @@ namespace rtx {
 // ------------------------------------------------------------------------------------------------
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDev N, const int* nrays,
-                                                 int* nnodes, int* nnext, int spawn, int* overflow)
+                                                 int* nnodes, int spawn, int* overflow)  // nnodes[1] = the rays of the next generation
 {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     bool live = i < min(*nrays, L.cap);
@@ -44,9 +44,14 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
             if (k < w) { off0 += sh_alloc[k]; off1 += sh_alloc[nw + k]; off2 += sh_alloc[2 * nw + k]; }
             tot0 += sh_alloc[k]; tot1 += sh_alloc[nw + k]; tot2 += sh_alloc[2 * nw + k];
         }
-        if (threadIdx.x == 0) {  // (two atomics in flight together; slots the loop above does not read)
-            sh_alloc[3 * nw] = tot0 ? atomicAdd(nnodes, tot0) : 0;
-            sh_alloc[3 * nw + 1] = (tot1 + tot2) ? atomicAdd(nnext, tot1 + tot2) : 0;
+        if (threadIdx.x == 0) {
+            // ONE atomic for both counters: the nodes of this generation and the rays of the next are the two halves of an aligned
+            // 64-bit word (rtx_device.hip: d_cnt).  Atomics on one address are served one at a time, ~12 ns each: generation 0 of
+            // a 4K frame has 8,100 workgroups.  (Slots of sh_alloc the loop above does not read; no carry: counts stay below 2^31.)
+            const unsigned long long add = (unsigned long long)(unsigned)tot0 | ((unsigned long long)(unsigned)(tot1 + tot2) << 32);
+            const unsigned long long old = add ? atomicAdd(reinterpret_cast<unsigned long long*>(nnodes), add) : 0ull;
+            sh_alloc[3 * nw] = (int)(unsigned)old;
+            sh_alloc[3 * nw + 1] = (int)(unsigned)(old >> 32);
         }
         __syncthreads();
         const int base0 = sh_alloc[3 * nw], base1 = sh_alloc[3 * nw + 1];
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(kBlock) void k_aa_quantise4(const float* fimg, cons
 // counters of one chunk -> 64-bit frame totals
 __global__ void k_accumulate(const int* cnt, unsigned long long* totals, int levels)
 {
-    int k = threadIdx.x;
-    if (k < 2 * levels) totals[k] += (unsigned long long)cnt[k];
+    int k = threadIdx.x;  // totals: rays per level, then nodes per level; cnt: rays of level k at [2k + 1], nodes at [2k + 2]
+    if (k < 2 * levels) totals[k] += (unsigned long long)cnt[k < levels ? 2 * k + 1 : 2 * (k - levels) + 2];
 }
 
 

@@ -47,7 +47,7 @@ template __global__ void k_closest<false>(SceneDev, LevelDev, const int*, unsign
 template __global__ void k_closest<true>(SceneDev, LevelDev, const int*, unsigned long long*);
 template __global__ void k_shadow<false>(SceneDev, LevelDev, const int*, unsigned long long*);
 template __global__ void k_shadow<true>(SceneDev, LevelDev, const int*, unsigned long long*);
-template __global__ void k_setup<256>(SceneDev, LevelDev, LevelDev, const int*, int*, int*, int, int*);
-template __global__ void k_setup<1024>(SceneDev, LevelDev, LevelDev, const int*, int*, int*, int, int*);
+template __global__ void k_setup<256>(SceneDev, LevelDev, LevelDev, const int*, int*, int, int*);
+template __global__ void k_setup<1024>(SceneDev, LevelDev, LevelDev, const int*, int*, int, int*);
 #endif
 }
