@@ -41,7 +41,7 @@ namespace rtx {
 // on top of it, zero directions -- take the transposed scan over every shadow caster, as in k_shadow_pass.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCellLevels = 32;
-constexpr int kCellCap = 2048;   // entries one build wave sorts in LDS; longer lists are stored unsorted with dneed = -1
+constexpr int kCellCap = 512;    // entries one build wave sorts in LDS; longer lists are stored unsorted with dneed = -1
 constexpr int kCellPad = 4;      // readable entries behind the last list (the walk loads four at a time)
 
 __host__ __device__ __forceinline__ F3 oct_decode(float qx, float qy)
@@ -171,9 +171,9 @@ __device__ __forceinline__ bool tri_cell_reject(const CellCone& K, const F3 Lp, 
 // carries its own length.  A table that does not fit `cap` entries leaves oc = { 0, 0 } for the cells that came too late and the cursor
 // at what the whole table needs: the host builds it again at that size (or takes a coarser map) -- a count pass in front, as the
 // first version had, cost as much as the fill (C4: 2.2 of 6.4 ms; context creation is inside a scene's first rtx_render_rgb8 call).
-// (Four cells a workgroup, one atomic for the four: atomics on one address are served one at a time, ~12 ns each, and a million of
+// (Sixteen cells a workgroup, one atomic for the lot: atomics on one address are served one at a time, ~12 ns each, and a million of
 // them -- one per cell of C4's map -- took 12 ms where the build itself takes 3.)
-constexpr int kCellsPerGroup = 4;
+constexpr int kCellsPerGroup = 16;
 // CAMERA mode (cam.on; round 3): the same table for the PRIMARY rays, which all leave one point as the shadow rays of a light all pass
 // through one -- apex = the camera, one "light", cells keyed by the ray's own direction, entries = every primitive (the closest-hit
 // cluster set) whose exact test can accept some ray of the cell:

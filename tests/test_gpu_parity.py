@@ -303,7 +303,9 @@ def _camera_case(kind):
         rec.append("sphere 0 0 0 30  %s  0 0 1 0 8" % mat)   # the camera sits inside this one
         rec.append("polygon 4 -6 -3 -6  6 -3 -6  6 -3 -40  -6 -3 -40  %s  0.5 0 1 8" % mat)
     elif kind == "long_list":
-        # 2,500 small spheres behind one another: the middle cells' lists exceed what a build wave sorts (their rays take the scan)
+        # 2,500 small spheres behind one another: the middle cells' lists exceed what a build wave sorts (their rays take the scan);
+        # a third light on their line: ITS cells along the line overflow too (a light's list is then stored unsorted, dneed = -1)
+        rec.append("light 0.01 0.02 8 0.6 0.6 0.6")
         for i in range(2500):
             rec.append("sphere %.4f %.4f %.4f 0.3  %s  %s 1 0 8" % (rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), -5.0 - 0.1 * i, mat, "0.5 0" if i % 50 == 0 else "0 0"))
     elif kind == "many_polygons":
