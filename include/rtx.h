@@ -328,6 +328,14 @@ int  rtx_cluster_runs(const rtx_scene* scene, int32_t which, int32_t* order, flo
 int  rtx_light_cell(const float* dir3, int32_t G);
 int  rtx_cell_cone(int32_t cell, int32_t G, float* out7);
 
+/* The tests k_closest_lanes runs on the spheres { c, R } of its hierarchy (rtx_closest.hip.h), the kernel's own functions compiled
+ * for the host: for a ray (origin3, unit dir3) out3 = { cone_slack, cone_slack_front, cone_slack_cull with the far limit lr }; a
+ * value with the sign bit set means the sphere and everything in it is skipped.  cone_slack_cull skips what lies wholly beyond
+ * lr = 1.015625 L + 1e-5 guard, L = the largest t at which a hit could still change the ray's state; tests/test_far_cull.py
+ * checks against the reference's own sphere arithmetic that no hit at t <= L is ever inside a skipped sphere.  No counterpart
+ * in the reference. */
+int  rtx_cone_tests(const float* origin3, const float* dir3, const float* sphere4, float lr, float* out3);
+
 /* ---- host side kept from the reference (C++ inside, C outside) ------------------------------ */
 /* Scene-file reader with the grammar and stream semantics of parseinput (raytracing.cpp:851-979),
  * records zero-filled before parsing.  Polygons keep parseinput's rules: normal from the

@@ -10,6 +10,6 @@ repo-root shim ``rtxamd`` (``import rtxamd as rt``).
 """
 from . import host, scenegen  # noqa: F401  (bands imports torch: import it explicitly)
 from .host import (  # noqa: F401
-    Context, Params, RtxError, Scene, Stats, band_rows, device_count, lib, load_scene, filter_records, affine_shadow_records, triangle_edge_records, cluster_records, cluster_runs,
+    Context, Params, RtxError, Scene, Stats, band_rows, device_count, lib, load_scene, filter_records, affine_shadow_records, triangle_edge_records, cluster_records, cluster_runs, cone_tests,
     render_f32, render_rgb8, render_rgb8_noalloc, write_ppm,
 )

@@ -319,7 +319,7 @@ __device__ __forceinline__ bool packet_test(const Packet& P, float4 b)
 // (Round 3: written with FMAs -- 15 instructions instead of 28.  These are BOUNDS, not the reference's arithmetic: every term
 // keeps its slack -- 4e-6 C^2 under the cancellation, 1.00001 on the radius and on the right-hand side, cosE2 rounded down,
 // sinE rounded up -- and a fused product only drops a rounding of 6e-8 relative, a sixtieth of the smallest of them.)
-__device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
+__host__ __device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
 {
     const float cosE2 = 0.9999783f;  // (cos(3.7e-3) - 4e-6)^2 rounded down
     const float sinE = 3.705e-3f;    // sin(3.7e-3) rounded up, + 4e-6
@@ -333,7 +333,7 @@ __device__ __forceinline__ float cone_slack(F3 o, F3 n, float4 b)
 
 // cone_slack with the half-space behind the origin taken out (see filt_front; b = { c, R } encloses bounding
 // spheres of plain primitives only): sign bit set = no member can be hit.
-__device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
+__host__ __device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
 {
     const float cosE2 = 0.9999783f;
     const float sinE = 3.705e-3f;
@@ -359,7 +359,7 @@ __device__ __forceinline__ float cone_slack_front(F3 o, F3 n, float4 b)
 //     and for an enclosing sphere (as_m <= as + R, r_m <= R): t >= as (1 - 1.5e-3) - R (1 + 3e-3) - 1e-6 guard.
 // The test as * (1 - 1/128) - R * (1 + 1/64) > 1.015625 L + 1e-5 guard therefore puts every such t strictly above L, with the
 // rounding of as itself (4u |c - o| <= 1e-6 guard) a tenth of the absolute term.  R = +inf and NaN compare false: no cull.
-__device__ __forceinline__ float cone_slack_cull(F3 o, F3 n, float4 b, float lr)
+__host__ __device__ __forceinline__ float cone_slack_cull(F3 o, F3 n, float4 b, float lr)
 {
     const float cosE2 = 0.9999783f;
     const float sinE = 3.705e-3f;

@@ -1834,6 +1834,19 @@ int rtx_cell_cone(int32_t cell, int32_t G, float* out7)
     return RTX_OK;
 }
 
+// The per-ray traversal's tests on an enclosing sphere { c, R }, the kernel's own functions compiled for the host: out3 = { cone_slack,
+// cone_slack_front, cone_slack_cull(lr) } (sign bit set = the sphere is skipped).  Pure host function.
+int rtx_cone_tests(const float* origin3, const float* dir3, const float* sphere4, float lr, float* out3)
+{
+    if (!origin3 || !dir3 || !sphere4 || !out3) return RTX_E_INVALID_ARG;
+    const F3 o = f3(origin3[0], origin3[1], origin3[2]), n = f3(dir3[0], dir3[1], dir3[2]);
+    const float4 b = make_float4(sphere4[0], sphere4[1], sphere4[2], sphere4[3]);
+    out3[0] = cone_slack(o, n, b);
+    out3[1] = cone_slack_front(o, n, b);
+    out3[2] = cone_slack_cull(o, n, b, lr);
+    return RTX_OK;
+}
+
 void rtx_release_cached_context(void)
 {
     {

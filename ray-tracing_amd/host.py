@@ -143,6 +143,7 @@ SYMBOLS = {
     "rtx_affine_shadow_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_triangle_edge_records": (C.c_int, [C.POINTER(SceneView), C.c_void_p, C.c_int32]),
     "rtx_cluster_records": (C.c_int, [C.POINTER(SceneView), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "rtx_cone_tests": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "rtx_cluster_runs": (C.c_int, [C.POINTER(SceneView), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
     "rtx_scene_load_legacy": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(SceneView))]),
@@ -285,6 +286,14 @@ def cluster_records(scene, which=0):
         _check(lib().rtx_cluster_records(scene.ptr, which, cl.ctypes.data, sub.ctypes.data, mem.ctypes.data, idx.ctypes.data, n),
                "rtx_cluster_records")
     return cl, sub, mem, idx
+
+
+def cone_tests(origin, direction, sphere, lr):
+    """(cone_slack, cone_slack_front, cone_slack_cull(lr)) of the per-ray traversal for one ray and one sphere { c, R } (rtx_cone_tests)."""
+    o = np.ascontiguousarray(origin, dtype=np.float32); d = np.ascontiguousarray(direction, dtype=np.float32)
+    b = np.ascontiguousarray(sphere, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
+    _check(lib().rtx_cone_tests(o.ctypes.data, d.ctypes.data, b.ctypes.data, float(np.float32(lr)), out.ctypes.data), "rtx_cone_tests")
+    return out
 
 
 def cluster_runs(scene, which=0):
