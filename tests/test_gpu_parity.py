@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES
+from conftest import ROOT, SCENES
 from parity import assert_rgb8_parity, raw_equal_mask
 
 pytestmark = pytest.mark.gpu
@@ -398,3 +398,23 @@ def test_random_cameras_culled_equals_exact(rt, gpu, tmp_path, seed):
     same = raw_equal_mask(a, b)
     assert same.all(), "%d pixels differ" % int((~same).sum())
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_lights_shadow_stage_culled_equals_exact(rt, gpu, tmp_path, seed):
+    """Random scenes in front of two wall triangles (every primary ray hits something), 24 random lights each -- inside the cloud,
+    far outside, behind the walls, at the camera -- depth 1 (tools/dbg/fuzz_shadow.py, which runs more seeds): the (light, cell)
+    tables and their walk against the exact-only kernels, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_shadow", os.path.join(ROOT, "tools", "dbg", "fuzz_shadow.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    p = tmp_path / ("fuzzsh_%d.txt" % seed)
+    fz.make_scene(str(p), seed)
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(480, 270, 1))
+    b, sb = rt.render_f32(sc, rt.Params.make(480, 270, 1, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert sa.shadow_form == 1 and sa.hits > 100000
