@@ -418,3 +418,23 @@ def test_random_lights_shadow_stage_culled_equals_exact(rt, gpu, tmp_path, seed)
     assert same.all(), "%d pixels differ" % int((~same).sum())
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
     assert sa.shadow_form == 1 and sa.hits > 100000
+
+
+@pytest.mark.parametrize("seed", [0, 4, 13])
+def test_scaled_scenes_culled_equals_exact(rt, gpu, tmp_path, seed):
+    """Random scenes with every length multiplied by 1e-2, 1e3 and 1e2 (tools/dbg/fuzz_scale.py, which runs more seeds and scales):
+    the library's absolute constants -- the reference's own 1e-4 origin bias, the tables' delta, the guard box -- on scenes far
+    smaller and far larger than the benchmark's, against the exact-only kernels, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_scale", os.path.join(ROOT, "tools", "dbg", "fuzz_scale.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    p = tmp_path / ("fuzzsc_%d.txt" % seed)
+    _, _, _, md = fz.make_scene(str(p), seed)
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(400, 225, md))
+    b, sb = rt.render_f32(sc, rt.Params.make(400, 225, md, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert sa.hits > 10000
