@@ -876,19 +876,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_cells(SceneDev S, CamTab T, 
     int best = h.best;
     int tflag = (best >= 0 && best < S.ns && aliveList) ? kTFlag : 0;
     const bool slow = live && (h.overflow || !covered);
-    if (__any(slow)) {
-        const F3 fo = abn ? f3(1e18f, 0.0f, 0.0f) : o;
-        const F3 fd = abn ? f3(0.0f, 0.0f, 0.0f) : f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale);
-        HitAcc hs;
-        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
-        const int nprim = S.ns + S.nt + S.np;
-        for (int k = 0; k < nprim; k++) {
-            const float4 b = S.bounds[k];
-            if (slow && !abn) ex_add(ex, EX_FILT);
-            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs, ex);
-        }
-        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
-    }
+    ordered_scan(S, slow, abn, o, d, nd, nearest, best, tflag, ex);
     if (inq) {
         L.t[i] = nearest;
         L.prim[i] = (best < 0) ? -1 : (best | tflag);

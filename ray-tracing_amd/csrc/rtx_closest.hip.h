@@ -144,6 +144,61 @@ __device__ __forceinline__ void exact_closest(const SceneDev& S, int k, F3 o, F3
 }
 
 
+// The ordered scan over every primitive (raytracing.cpp:385-418 as it stands) for the FLAGGED lanes of a wave: rays whose list of
+// affine-sphere hits overflowed (LexAcc), rays no table or filter covers.  Few flagged lanes -- the usual case: one ray in a wave
+// of a scene whose affine spheres overlap five deep -- go one RAY at a time: the wave's 64 lanes filter 64 primitives a step and the
+// survivors take the exact test in index order, wave-uniform (157 steps for 10,000 primitives where the flagged lane alone took
+// 10,000: one such ray held its whole launch for 2 ms, tools/dbg/perf_survey.py "dense").  Many flagged lanes (a camera cell without
+// a list: all 64) scan each for itself, 64 rays a step.  Same tests on the same operands in the same order either way.
+__device__ __forceinline__ void ordered_scan(const SceneDev& S, const bool slow, const bool abn, const F3 o, const F3 d, const F3 nd,
+                                             float& nearest, int& best, int& tflag, Exec* ex)
+{
+    const unsigned long long sm0 = __ballot(slow);
+    if (sm0 == 0ull) return;  // wave-uniform
+    const int nprim = S.ns + S.nt + S.np;
+    const int lane = threadIdx.x & 63;
+    if (__popcll(sm0) > 16) {
+        const F3 fo = abn ? f3(1e18f, 0.0f, 0.0f) : o;
+        const F3 fd = abn ? f3(0.0f, 0.0f, 0.0f) : f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale);
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        for (int k = 0; k < nprim; k++) {
+            const float4 b = S.bounds[k];
+            if (slow && !abn) ex_add(ex, EX_FILT);
+            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs, ex);
+        }
+        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+        return;
+    }
+    const unsigned long long am = __ballot(abn);
+    auto bc = [](float v, int r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+    for (unsigned long long sm = sm0; sm != 0ull; sm &= sm - 1) {
+        const int r = __ffsll((long long)sm) - 1;
+        const bool rabn = ((am >> r) & 1ull) != 0ull;
+        const F3 ro = f3(bc(o.x, r), bc(o.y, r), bc(o.z, r)), rd = f3(bc(d.x, r), bc(d.y, r), bc(d.z, r)), rn = f3(bc(nd.x, r), bc(nd.y, r), bc(nd.z, r));
+        const F3 fo = ro, fd = f3(rn.x * kDirScale, rn.y * kDirScale, rn.z * kDirScale);
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        Exec tmp;
+        Exec* const te = ex ? &tmp : nullptr;  // every lane runs the survivors' tests: counted once, for the ray's own lane
+        ex_zero(te);
+        for (int k0 = 0; k0 < nprim; k0 += 64) {
+            const int k = k0 + lane;
+            bool pass = k < nprim;
+            if (pass && !rabn) pass = !(filt(fo, fd, S.bounds[k]) < 0.0f);
+            for (unsigned long long pm = __ballot(pass); pm != 0ull; pm &= pm - 1)
+                exact_closest(S, k0 + (__ffsll((long long)pm) - 1), ro, rd, rn, hs, te);
+        }
+        if (lane == r) {
+            nearest = hs.nearest; best = hs.best; tflag = hs.tflag;
+            if (ex) {
+                if (!rabn) ex->n[EX_FILT] += (unsigned)nprim;
+                for (int q = 0; q < EX_KINDS; q++) ex->n[q] += tmp.n[q];
+            }
+        }
+    }
+}
+
 // exact_closest for a wave-uniform primitive k whose hot record sits in lane u's registers
 __device__ __forceinline__ void exact_closest_bcast(const SceneDev& S, int k, const PrimRec& pr, int u, bool pass, F3 o, F3 d, F3 nd, HitAcc& h, Exec* ex = nullptr)
 {
@@ -1042,19 +1097,7 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     int best = h.best;
     int tflag = (best >= 0 && best < S.ns && aliveList) ? kTFlag : 0;
     const bool slow = live && h.overflow;
-    if (__any(slow)) {
-        const F3 fo = abn ? f3(1e18f, 0.0f, 0.0f) : o;
-        const F3 fd = abn ? f3(0.0f, 0.0f, 0.0f) : f3(nd.x * kDirScale, nd.y * kDirScale, nd.z * kDirScale);
-        HitAcc hs;
-        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
-        const int nprim = S.ns + S.nt + S.np;
-        for (int k = 0; k < nprim; k++) {
-            const float4 b = S.bounds[k];
-            if (slow && !abn) ex_add(ex, EX_FILT);
-            if (slow && (abn || !(filt(fo, fd, b) < 0.0f))) exact_closest(S, k, o, d, nd, hs, ex);
-        }
-        if (slow) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
-    }
+    ordered_scan(S, slow, abn, o, d, nd, nearest, best, tflag, ex);
     if (S.pstat) {
         const unsigned long long sl = __ballot(slow);
         const unsigned long long ab = __ballot(abn);

@@ -523,7 +523,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         // start beyond to pass the entry (rtx_cells.hip.h): count, scan, fill.  Not in arena mode (its size is unknown
         // before the count) and not for the exact-only / counting frames, which trace no culled shadow rays.
         c->cells = CellTab{};
-        bool want_cells = !c->arena && c->S.nl > 0 && c->S.sncl > 0 && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
+        // (a scene whose shadow casters are ALL affine spheres still takes the tables: its plain lists are empty, and the packet form's
+        // strip test over a bit-mask union of thousands of affine spheres is what it was never meant for -- 3,000 general affine
+        // spheres at 4K: 239 ms a frame in the packet form, tools/dbg/perf_survey.py)
+        bool want_cells = !c->arena && c->S.nl > 0 && (c->S.sncl > 0 || c->S.naff > 0) && !(params->flags & (RTX_F_EXACT_ONLY | RTX_F_COUNT_TESTS));
         if (const char* e = ab_knob("RTX_CELLS")) want_cells = want_cells && std::atoi(e) != 0;
         if (want_cells) {
             // The tables' range: the far corner of the box of the shadow casters themselves (an affine sphere as it sits for a

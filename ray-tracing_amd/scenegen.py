@@ -57,7 +57,7 @@ def write_scene(path, nspheres, ntriangles, lights, seed=SEED, zfar=-120.0, frac
     """Write one scene; returns the number of records.  `lights` is a list of (x,y,z,r,g,b).
     affine = "diag": scale matrices (the benchmark scenes); "general": rotation x scale matrices, one in 16
     with a translation row and one in 32 singular (parity stress scenes; drawn from a second generator so
-    the other records do not change)."""
+    the other records do not change); "rotated": rotation x scale matrices, none of those."""
     rng = SplitMix64(seed)
     rng2 = SplitMix64(seed ^ 0x5DEECE66D)
     lines = []
@@ -80,7 +80,7 @@ def write_scene(path, nspheres, ntriangles, lights, seed=SEED, zfar=-120.0, frac
             s = ("sphere %s %s %s %s %s %s %s 1.2 %d %s" %
                  (_fs(c[i]), _f(r[i]), _fs(col[i]), _fs(dif[i]), _fs(spe[i]), _f(refl[i]), _f(refr[i]),
                   1 if xf[i] else 0, _f(expo[i])))
-            if xf[i] and affine == "general":
+            if xf[i] and affine in ("general", "rotated"):
                 q = rng2.uniform(-1, 1, 4)
                 q = q / max(float(np.linalg.norm(q)), 1e-6)
                 a, b, cc, d = (float(v) for v in q)
@@ -90,7 +90,9 @@ def write_scene(path, nspheres, ntriangles, lights, seed=SEED, zfar=-120.0, frac
                 M = R * np.asarray(sc[i], dtype=np.float64)[None, :]
                 kind = float(rng2.uniform(0, 1, 1)[0])
                 t = np.zeros(3)
-                if kind < 1.0 / 16:
+                if affine == "rotated":
+                    pass
+                elif kind < 1.0 / 16:
                     t = np.asarray(rng2.uniform(-0.5, 0.5, 3), dtype=np.float64)
                 elif kind < 1.0 / 16 + 1.0 / 32:
                     M[2] = M[0] * 2.0  # singular

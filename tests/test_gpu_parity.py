@@ -420,6 +420,26 @@ def test_random_lights_shadow_stage_culled_equals_exact(rt, gpu, tmp_path, seed)
     assert sa.shadow_form == 1 and sa.hits > 100000
 
 
+@pytest.mark.parametrize("affine", ["rotated", "diag"])
+def test_ordered_scan_of_flagged_rays(rt, gpu, tmp_path, affine):
+    """Affine spheres overlapping many deep (3,000 spheres, four in five of them affine, in a box of 20 x 12 x 30): rays whose list
+    of affine-sphere hits overflows (LexAcc, four entries) take the ordered scan over every primitive -- one ray at a time with the
+    wave's lanes over the primitives when few lanes of a wave are flagged (ordered_scan, rtx_closest.hip.h), each lane for itself
+    when many are.  Culled == exact-only, bit for bit, and the flagged rays exist (rtx_stats.packet_stats[1], low half: 20 secondary
+    rays with rotated ellipsoids, 1,386 with axis-aligned ones; tools/dbg/flagged_probe.py)."""
+    p = tmp_path / "dense_affine.txt"
+    rt.scenegen.write_scene(str(p), 3000, 500, rt.scenegen.lights_c4(), seed=77, box=(10.0, 6.0), zfar=-60.0, znear=-30.0,
+                            frac_affine=0.8, frac_reflective=0.6, radius=(0.5, 3.0), affine=affine)
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(640, 360, 3, flags=rt.host.F_PACKET_STATS))
+    b, sb = rt.render_f32(sc, rt.Params.make(640, 360, 3, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    flagged = int(sa.packet_stats[1]) & 0xffffffff
+    assert flagged >= 10 and sa.rays_secondary > 10000, (flagged, sa.rays_secondary)
+
+
 @pytest.mark.parametrize("seed", [0, 4, 13])
 def test_scaled_scenes_culled_equals_exact(rt, gpu, tmp_path, seed):
     """Random scenes with every length multiplied by 1e-2, 1e3 and 1e2 (tools/dbg/fuzz_scale.py, which runs more seeds and scales):
