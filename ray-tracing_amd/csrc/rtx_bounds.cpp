@@ -100,6 +100,45 @@ void enclosing_circle(const double p[3][2], double& cx, double& cy, double& r)
     r = std::hypot(ax - cx, ay - cy);
 }
 
+// ||M||_2 of a 3 x 3 matrix, never below it: the largest eigenvalue of M^T M by cyclic Jacobi rotations (double; converged to
+// ~1e-15, returned with 1e-9 on top).  sqrt(||M||_1 ||M||_inf) -- what the bounds used before -- is up to sqrt(3) above it for a
+// rotated matrix: with both factors of a condition number that loose, most ROTATED ellipsoids failed "cond <= 8" and became
+// records every shadow ray tests (3,000 of them at 4K: 324 exact tests a shadow ray, tools/dbg/perf_survey.py "affine").
+double spectral_norm_up(const double M[3][3])
+{
+    double S[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) S[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            if (!std::isfinite(S[i][j])) return kInf;
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = std::fabs(S[0][1]) + std::fabs(S[0][2]) + std::fabs(S[1][2]);
+        if (off <= 1e-300 || off <= 1e-17 * (std::fabs(S[0][0]) + std::fabs(S[1][1]) + std::fabs(S[2][2]))) break;
+        for (int pp = 0; pp < 2; pp++)
+            for (int q = pp + 1; q < 3; q++) {
+                if (S[pp][q] == 0.0) continue;
+                const double theta = (S[q][q] - S[pp][pp]) / (2.0 * S[pp][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                const int r = 3 - pp - q;
+                const double spq = S[pp][q], srp = S[r][pp], srq = S[r][q];
+                S[pp][pp] -= t * spq; S[q][q] += t * spq;
+                S[pp][q] = S[q][pp] = 0.0;
+                S[r][pp] = S[pp][r] = c * srp - sn * srq;
+                S[r][q] = S[q][r] = sn * srp + c * srq;
+            }
+    }
+    // (Gershgorin on what is left of the off-diagonal part: an upper bound whether or not the sweeps converged)
+    double lam = 0;
+    for (int i = 0; i < 3; i++) {
+        double g = S[i][i];
+        for (int j = 0; j < 3; j++) if (j != i) g += std::fabs(S[i][j]);
+        lam = std::max(lam, g);
+    }
+    return std::sqrt(std::max(lam, 0.0)) * (1.0 + 1e-9);
+}
+
 }  // namespace
 
 BoundSphere bound_sphere_plain(const rtx_sphere& s)
@@ -146,7 +185,7 @@ BoundSphere bound_sphere_affine(const rtx_sphere& s, const rtx_xmatrix& im, doub
     B[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
     B[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
     B[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
-    double nB = norm2_bound(B);
+    double nB = std::min(norm2_bound(B), spectral_norm_up(B));  // the bounding sphere's radius is r ||A^-1||_2
     if (!std::isfinite(nB) || nA * nB > 1e3) return always_pass();  // ill-conditioned: not worth a bound
     D3 c = d3(s.center);
     double r = std::fabs((double)s.radius);
@@ -202,7 +241,12 @@ AffineShadowRec affine_shadow_record(const rtx_sphere& s, const rtx_xmatrix& im,
             binf = std::max(binf, std::fabs(B[i][0]) + std::fabs(B[i][1]) + std::fabs(B[i][2]));
             b1 = std::max(b1, std::fabs(B[0][i]) + std::fabs(B[1][i]) + std::fabs(B[2][i]));
         }
-        nB = std::sqrt(b1 * binf);
+        // nA must bound the matrix of ABSOLUTE values (the rounding of ld*A is entry by entry); A^-1 enters as 1 / sigma_min(A) alone
+        double absA[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) absA[i][j] = std::fabs(A[i][j]);
+        nA = std::min(nA, spectral_norm_up(absA));
+        nB = std::min(std::sqrt(b1 * binf), spectral_norm_up(B));
         if (!(nA * nB <= 8.0)) return r;
     }
     double rad = std::fabs((double)s.radius);

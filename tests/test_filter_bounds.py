@@ -206,6 +206,73 @@ def test_affine_shadow_filter(rt, oracle, tmp_path):
         assert not (acc & ~P).any()
 
 
+@pytest.mark.parametrize("affine", ["rotated", "general"])
+def test_affine_shadow_filter_rotated_matrices(rt, oracle, tmp_path, affine):
+    """The same for ROTATED ellipsoids (rotation x scale, scale 0.5 .. 2: condition number <= 4).  The record's "cond <= 8" test
+    takes spectral norms (rtx_bounds.cpp: spectral_norm_up) -- with sqrt(||.||_1 ||.||_inf) for both factors most of these were
+    records every shadow ray tests -- so every rotated sphere must now be bounded, and the filter must still keep every pair the
+    reference accepts: rays are aimed in OBJECT space (td = normalize(ld * A) towards the centre, ld = td * A^-1)."""
+    p = tmp_path / "rot.txt"
+    rt.scenegen.write_scene(str(p), 300, 0, rt.scenegen.lights_c4(), frac_affine=1.0, affine=affine, seed=321)
+    sc = rt.load_scene(str(p))
+    v = sc.view
+    rec = rt.affine_shadow_records(sc)
+    assert rec.shape[0] == v.nspheres == 300
+    bounded = np.isfinite(rec[:, 12])
+    # (the matrix a record holds is what the reference's inverseMatrix makes of the file's -- not always its inverse, so a few
+    # records do exceed the bound; "general": one in 16 has a translation row, one in 32 is singular)
+    assert bounded.mean() > (0.9 if affine == "rotated" else 0.8)
+    for k in range(300):
+        A = rec[k, :9].astype(np.float64).reshape(3, 3)
+        sv = np.linalg.svd(A, compute_uv=False)
+        if sv[2] > 0 and np.linalg.svd(np.abs(A), compute_uv=False)[0] / sv[2] <= 7.99 and not np.any(rec[k, 9:12] != rec[k, 9:12]):
+            xm = v.spheres[k].mat
+            if xm.d.x == 0 and xm.d.y == 0 and xm.d.z == 0:
+                assert bounded[k], "record %d: || |A| ||_2 / sigma_min = %.3f <= 8 but unbounded" % (k, np.linalg.svd(np.abs(A), compute_uv=False)[0] / sv[2])
+    rng = np.random.default_rng(9)
+    n = 6000
+    o = rng.uniform(-50, 50, (n, 3)).astype(f32)
+    d = np.zeros((n, 3))
+    for i in range(n):
+        k = i % 300
+        A = rec[k, :9].astype(np.float64).reshape(3, 3)
+        s = v.spheres[k]
+        c = np.array([s.center.x, s.center.y, s.center.z]) + rng.normal(size=3) * abs(s.radius) * rng.choice([0.2, 0.9, 1.0, 1.1, 3.0])
+        q = c - o[i]
+        try:
+            ld = q @ np.linalg.inv(A)
+        except np.linalg.LinAlgError:
+            ld = q
+        d[i] = ld / max(np.linalg.norm(ld), 1e-30)
+    d = d.astype(f32)
+    acc = oracle.accept_matrix(sc, o, d, shadow=True).astype(bool)
+    P = affine_shadow_pass(rec, o, d)
+    assert acc.sum() > 2000
+    assert not (acc & ~P).any(), "filter rejected %d accepted pairs" % int((acc & ~P).sum())
+    assert P[:, bounded].mean() < 0.2   # and it is a filter
+    # closest-hit records (origin AND direction mapped, rt.cpp:387-398): the world-space bounding sphere takes its radius from
+    # ||A^-1||_2 (spectral too); rays aimed at points of the ellipsoid as it lies in the world, p = (c + r u) A^-1
+    main, _ = rt.filter_records(sc)
+    tg, og = [], []
+    for k in range(300):
+        A = rec[k, :9].astype(np.float64).reshape(3, 3)
+        if abs(np.linalg.det(A)) < 1e-9:
+            continue
+        s = v.spheres[k]
+        u = rng.normal(size=(12, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        pts = (np.array([s.center.x, s.center.y, s.center.z]) + u * abs(s.radius) * rng.choice([0.0, 0.9, 0.999, 1.001, 1.3], size=(12, 1))) @ np.linalg.inv(A)
+        tg.append(pts); og.append(pts + rng.normal(size=pts.shape) * rng.choice([0.5, 5.0, 40.0], size=(12, 1)))
+    tg = np.concatenate(tg); og = np.concatenate(og)
+    ok = np.all(np.abs(og) < 1e3, axis=1) & np.all(np.abs(tg) < 1e3, axis=1)
+    og, tg = og[ok], tg[ok]
+    dg = tg - og
+    dg /= np.maximum(np.linalg.norm(dg, axis=1, keepdims=True), 1e-30)
+    acc2 = oracle.accept_matrix(sc, og.astype(f32), dg.astype(f32)).astype(bool)
+    P2 = filter_pass(main, og.astype(f32), dg.astype(f32))
+    assert acc2.sum() > 1500
+    assert not (acc2 & ~P2).any(), "closest-hit filter rejected %d accepted pairs" % int((acc2 & ~P2).sum())
+
+
 def test_direction_cell_chord_bound():
     """k_affine_cells (rtx_shadow.hip.h) takes every unit direction of a cell of the G x G octahedral map to lie within
     3 sqrt(2) / G of the direction of the cell's centre.  Checked here on a numpy restatement of light_cell and of
