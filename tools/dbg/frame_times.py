@@ -1,3 +1,4 @@
+"""Per-kernel event times of the 4K C4 frame at depth 1 and depth 5 (RTX_F_TIME_KERNELS)."""
 import sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtxamd as rt

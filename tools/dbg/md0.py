@@ -1,3 +1,4 @@
+"""Per-kernel event times of C4 at four frame sizes (640x480 ... 4K) for one depth.  usage: md0.py [max_depth]"""
 import sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtxamd as rt

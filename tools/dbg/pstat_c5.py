@@ -1,3 +1,4 @@
+"""Packet statistics of the C5 scene at 1080p (packet form of the shadow stage): blocks, fallbacks, batches and survivors per block."""
 import sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtxamd as rt
