@@ -174,7 +174,8 @@ typedef struct rtx_stats {
     float    ms_shadow;         /*                          ... of the shadow any-hit launches (k_shadow_pass) */
     /* RTX_F_PACKET_STATS only.  [0..3] closest-hit: generation 0 adds {waves, waves that made a packet,
      * 64-record batches tested, primitives kept}, later generations {waves, rays sent to the ordered scan
-     * | abnormal rays << 32, unused, exact tests}.  [4..7] shadow pass: {lane blocks traced, blocks
+     * | abnormal rays << 32, unused, exact tests}; generation 0 on the camera's table (k_primary_cells) adds to [2] only:
+     * {primary rays sent to the ordered scan over their own list | over every primitive << 32}.  [4..7] shadow pass: {lane blocks traced, blocks
      * that made a packet | rays traced transposed << 32, 64-record batches tested, plain primitives kept | affine spheres kept << 32} */
     uint64_t packet_stats[8];
     int32_t  launches_closest;  /* launches behind ms_closest / ms_shadow */

@@ -327,7 +327,9 @@ __global__ __launch_bounds__(64 * kCellsPerGroup) void k_cells_build(SceneDev S,
             int rank = 0;
             for (int j = 0; j < n; j++) {
                 const float kj = __int_as_float(buf[j].y);
-                rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+                // (ties: by position; the camera's lists by PRIMITIVE INDEX -- each of their two parts, affine spheres and the rest, is
+                // then in file order, which the ordered scan of a flagged primary ray merges: k_primary_cells)
+                rank += (kj < key || (kj == key && (cam.on ? buf[j].x < e.x : j < i))) ? 1 : 0;
             }
             ent[(size_t)base + rank] = e;
         }
@@ -796,6 +798,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_cells(SceneDev S, CamTab T, 
         pos = oc.x; end = oc.x + oc.y;
         if (oc.y < 0) { covered = false; end = pos; }
     }
+    const int beg = pos;
+    int mid = pos;  // where the list's affine spheres end (known after walk 0)
     lds_fence();
     LexAcc h;
     h.nearest = kMaxT; h.best = -1; h.overflow = false;
@@ -848,6 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_cells(SceneDev S, CamTab T, 
             if (nD >= 64) run_D(64);
         }
         while (nD > 0) run_D(nD);
+        if (walk == 0) mid = pos;
     }
     bool aliveList = false;
 #pragma unroll
@@ -855,8 +860,32 @@ __global__ __launch_bounds__(kBlock) void k_primary_cells(SceneDev S, CamTab T, 
     float nearest = h.nearest;
     int best = h.best;
     int tflag = (best >= 0 && best < S.ns && aliveList) ? kTFlag : 0;
-    const bool slow = live && (h.overflow || !covered);
+    // A flagged ray WITH a list (its affine-sphere hits overflowed LexAcc) takes the reference's ordered scan over that list: it holds
+    // every primitive whose exact test can accept the ray, its two parts each in file order (k_cells_build), merged here by index.
+    // Neighbouring primary rays overflow together -- whole waves in a scene whose affine spheres overlap five deep -- and the scan
+    // over every primitive cost such a wave 10,000 steps where its lists hold some forty entries (perf_survey.py "dense": the
+    // primary stage 1.99 -> 0.33 ms, the frame 3.29 -> 1.58).
+    const bool slow_list = live && covered && h.overflow;
+    if (__any(slow_list)) {
+        HitAcc hs;
+        hs.nearest = kMaxT; hs.best = -1; hs.tflag = 0; hs.txf = kMaxT;
+        int pa = beg, pb = mid;
+        while (__any(slow_list && (pa < mid || pb < end))) {
+            if (slow_list && (pa < mid || pb < end)) {
+                const int ka = (pa < mid) ? T.ent[pa].x : 0x7fffffff, kb = (pb < end) ? T.ent[pb].x : 0x7fffffff;
+                const int k = min(ka, kb);
+                if (ka <= kb) pa++; else pb++;
+                if (k >= 0 && k != 0x7fffffff) exact_closest(S, k, o, d, nd, hs, ex);
+            }
+        }
+        if (slow_list) { nearest = hs.nearest; best = hs.best; tflag = hs.tflag; }
+    }
+    const bool slow = live && !covered;
     ordered_scan(S, slow, abn, o, d, nd, nearest, best, tflag, ex);
+    if (S.pstat) {  // RTX_F_PACKET_STATS only
+        const unsigned long long sl = __ballot(slow_list), su = __ballot(slow);
+        if (lane == 0 && (sl | su)) atomicAdd(S.pstat + 2, (unsigned long long)__popcll(sl) + ((unsigned long long)__popcll(su) << 32));
+    }
     if (inq) {
         L.t[i] = nearest;
         L.prim[i] = (best < 0) ? -1 : (best | tflag);

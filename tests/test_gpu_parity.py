@@ -438,6 +438,9 @@ def test_ordered_scan_of_flagged_rays(rt, gpu, tmp_path, affine):
     assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
     flagged = int(sa.packet_stats[1]) & 0xffffffff
     assert flagged >= 10 and sa.rays_secondary > 10000, (flagged, sa.rays_secondary)
+    # ... and primary rays whose list of affine hits overflowed: they take the ordered scan over their camera cell's own list,
+    # merged by primitive index from its two parts (k_primary_cells)
+    assert (int(sa.packet_stats[2]) & 0xffffffff) >= 10, int(sa.packet_stats[2])
 
 
 @pytest.mark.parametrize("seed", [0, 4, 13])
