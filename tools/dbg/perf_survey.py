@@ -23,9 +23,23 @@ def floor(path):  # C4 over a mirror floor and in front of a wall: every primary
                   "triangle -400 -300 -130  400 -300 -130  400 300 -130  " + MAT % "0", "triangle -400 -300 -130  400 300 -130  -400 300 -130  " + MAT % "0"])
 
 
+def room(path):  # C4 inside a closed box of twelve wall triangles, the camera in it, two of the lights inside: no ray misses
+    G.write_scene(path, 5000, 5000, [(-30.0, 20.0, -20.0, .25, .25, .25), (30.0, 20.0, -100.0, .25, .25, .25), (0.0, 24.0, -60.0, .25, .25, .25), (0.0, -20.0, -40.0, .25, .25, .25)])
+    x0, x1, y0, y1, z0, z1 = -45.0, 45.0, -28.0, 28.0, -125.0, 5.0
+    c = [(x, y, z) for x in (x0, x1) for y in (y0, y1) for z in (z0, z1)]   # corner index = 4 ix + 2 iy + iz
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    recs = []
+    for qi, (a, b, cc, d) in enumerate(quads):
+        refl = ".3" if qi == 2 else "0"   # the floor reflects
+        for tri in ((a, b, cc), (a, cc, d)):
+            recs.append("triangle " + "  ".join("%g %g %g" % c[v] for v in tri) + "  " + MAT % refl)
+    append(path, recs)
+
+
 SCENES = {
     "c4": G.write_c4,
     "floor": floor,
+    "room": room,
     "dense": lambda p: G.write_scene(p, 5000, 5000, L4, box=(10.0, 6.0), zfar=-60.0, znear=-30.0),                 # everything overlaps
     "bigspheres": lambda p: G.write_scene(p, 2000, 0, L4, radius=(2.0, 8.0)),
     "longtri": lambda p: G.write_scene(p, 0, 5000, L4, edge=20.0),
