@@ -569,8 +569,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             const uint64_t max_entries = std::min<uint64_t>(((uint64_t)1 << 31) - 64, wbytes / 8 / sizeof(int2));
             int cells_tight = 1;  // entries by what the exact tests can accept (rtx_cells.hip.h); 0: by what the per-ray filter can pass
             if (const char* e = ab_knob("RTX_CELL_TIGHT")) cells_tight = std::atoi(e) ? 1 : 0;
-            // the guesses: 128 entries per caster and light for the plain table (C4 has 60, C5 85), 16,384 per affine sphere and
-            // light (C4: 14,150).  (The affine lists gain nothing from cells finer than 256 a side -- what they list is set by the slabs
+            // the guesses: 512 entries per caster and light for the plain table (C4 has 60, C5 85; lights inside the scene, large or
+            // long primitives take 200 ... 2,600 -- tools/dbg/perf_survey.py -- and a table that outgrows its guess is built twice:
+            // room that stays empty costs address space, a second build costs the first call 10 ... 30 ms), 16,384 per affine sphere
+            // and light (C4: 14,150).  (The affine lists gain nothing from cells finer than 256 a side -- what they list is set by the slabs
             // of origin distance, 13.8 M filter tests per C4 frame either way -- and 33 M lists take 29 ms to build against 6.)
             uint64_t tab_entries[2] = {0, 0}, tab_lists[2] = {0, 0};
             const bool verbose_tab = ab_knob("RTX_VERBOSE") != nullptr;
@@ -578,7 +580,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             const size_t tab_mark = c->allocs.size();
             {
                 TableOut to;
-                TableSpec ts{0, c->S.nl, G0, 8, kMaxLists, (uint64_t)c->S.nl * (uint64_t)c->S.nsb * 128, max_entries, d_dc, cells_tight, CamCells{}};
+                TableSpec ts{0, c->S.nl, G0, 8, kMaxLists, (uint64_t)c->S.nl * (uint64_t)c->S.nsb * 512, max_entries, d_dc, cells_tight, CamCells{}};
                 rc = build_cell_table(c, ts, &to);
                 c->cells.off = to.off; c->cells.ent = static_cast<const int2*>(to.ent); c->cells.G = to.G;
                 tab_entries[0] = to.entries; tab_lists[0] = to.lists;
@@ -607,14 +609,17 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             // Which form the shadow stage takes is measured at the end of creation (both forms render this context's frame) --
             // unless the answer is plain: forced by a flag, or lists so short that the walk cannot lose.  What a shadow ray pays in
             // the table form is its list (4 entries a step); the packet form lost on every frame measured whose lists average
-            // below 30 entries (C4: 2.3 plain and 3.4 affine, 2.5 against 4.2 ms; C5: 8 per list, 40 against 85 ms), so lists
-            // of <= 16 on average skip the measurement, the packet form's bit masks and its queues: 18 ms of a 74 ms creation.
+            // below 30 entries (C4: 2.3 plain and 3.4 affine, 2.5 against 4.2 ms; C5: 8 per list, 40 against 85 ms), and on every
+            // scene of tools/dbg/perf_survey.py that was still measured with lists of 16 ... 50 (a floor and walls: 22 per affine
+            // list; long triangles: 50 per plain list) -- the one scene the packets won, 3,000 rotated ellipsoids a seventh of
+            // which no record bounds, averages above 250.  So lists of <= 64 on average skip the measurement, the packet form's
+            // bit masks and its queues: 18 ms of C4's 74 ms creation at the time, 26 ... 71 ms of those scenes' 70 ... 130.
             {
                 int force = -1;
                 if (params->flags & RTX_F_SHADOW_PACKETS) force = 0;
                 if (params->flags & RTX_F_SHADOW_TABLES) force = 1;
                 if (const char* e = ab_knob("RTX_SHADOW_FORM")) force = std::atoi(e) ? 1 : 0;
-                const bool shortl = tab_entries[0] <= 16 * tab_lists[0] && tab_entries[1] <= 16 * tab_lists[1];
+                const bool shortl = tab_entries[0] <= 64 * tab_lists[0] && tab_entries[1] <= 64 * tab_lists[1];
                 c->form_early = c->use_cells && c->shadow_direct && (force == 1 || (force < 0 && shortl));
                 if (ab_knob("RTX_FORM_MEASURE") && force < 0) c->form_early = false;
             }
