@@ -304,6 +304,19 @@ static int build_cell_table(rtx_context* c, const TableSpec& T, TableOut* out)
             if (sum <= want) {
                 // the walks read a few entries past a list's end: { primitive -1, dneed NaN } (never taken), affine record 0 (masked)
                 HIPCHK(hipMemset(ent + (size_t)sum * esz, T.kind == 1 ? 0 : 0xff, esz * kCellPad));
+                // a generous guess must not stay in HBM for the life of the context: more than 256 MiB of unused room moves the
+                // entries into an allocation of their own size (C5's plain table: room for 512 M entries, 136 M used: 1 ms of copy)
+                if (want > 2 * sum && (want - sum) * esz > ((uint64_t)256 << 20) && !c->allocs.empty() && c->allocs.back() == (void*)ent) {
+                    char* fit = nullptr;
+                    const int rf = c->dalloc(&fit, ((size_t)sum + kCellPad) * esz);
+                    if (rf == RTX_OK) {
+                        HIPCHK(hipMemcpy(fit, ent, ((size_t)sum + kCellPad) * esz, hipMemcpyDeviceToDevice));
+                        const auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)ent);
+                        if (it != c->allocs.end()) { (void)hipFree(ent); c->allocs.erase(it); }
+                        ent = fit;
+                    } else if (rf == RTX_E_OOM) (void)hipGetLastError();  // no room for the copy: keep the large one
+                    else return rf;
+                }
                 out->off = off; out->ent = ent; out->G = G; out->attempt = attempt; out->entries = sum; out->lists = (uint64_t)ncell; out->room = want;
                 return RTX_OK;
             }
