@@ -443,6 +443,25 @@ def test_ordered_scan_of_flagged_rays(rt, gpu, tmp_path, affine):
     assert (int(sa.packet_stats[2]) & 0xffffffff) >= 10, int(sa.packet_stats[2])
 
 
+@pytest.mark.parametrize("seed", [1, 7])
+def test_dense_scenes_culled_equals_exact(rt, gpu, tmp_path, seed):
+    """Two seeds of tools/dbg/fuzz_dense.py (thousands of mostly affine spheres overlapping many deep, reflective and refractive,
+    depth 3 - 4): hundreds to thousands of secondary AND primary rays take the ordered scans; culled == exact-only, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_dense", os.path.join(ROOT, "tools", "dbg", "fuzz_dense.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    p = tmp_path / ("fuzzde_%d.txt" % seed)
+    _, _, md = fz.make_scene(str(p), seed)
+    sc = rt.load_scene(str(p))
+    a, sa = rt.render_f32(sc, rt.Params.make(480, 270, md, flags=rt.host.F_PACKET_STATS))
+    b, sb = rt.render_f32(sc, rt.Params.make(480, 270, md, flags=rt.host.F_EXACT_ONLY))
+    same = raw_equal_mask(a, b)
+    assert same.all(), "%d pixels differ" % int((~same).sum())
+    assert (sa.rays_secondary, sa.rays_shadow, sa.hits) == (sb.rays_secondary, sb.rays_shadow, sb.hits)
+    assert (int(sa.packet_stats[1]) & 0xffffffff) >= 100 and (int(sa.packet_stats[2]) & 0xffffffff) >= 1000
+
+
 @pytest.mark.parametrize("seed", [0, 4, 13])
 def test_scaled_scenes_culled_equals_exact(rt, gpu, tmp_path, seed):
     """Random scenes with every length multiplied by 1e-2, 1e3 and 1e2 (tools/dbg/fuzz_scale.py, which runs more seeds and scales):
