@@ -666,7 +666,7 @@ __device__ __forceinline__ void closest_packet(const SceneDev& S, const LevelDev
 //     FIRST; their hits form a list in which (j < k, t_j <= t_k) removes k, and every later hit of a
 //     plain sphere removes entries the same way.  The flag is "list not empty".  The list holds the
 //     staircase of affine hits (index up, t down), 4 entries; a fifth sends the ray to the ordered
-//     scan over every primitive at the end (wave-uniform loop, only the flagged lanes active).
+//     scan over every primitive at the end (ordered_scan above).
 // Rays the filter does not cover (ray_abnormal) take every cluster and every member.
 constexpr int kAffList = 4;
 
