@@ -1252,6 +1252,11 @@ constexpr size_t kPrefetchRays = (size_t)1 << 20;  // generation-0 frames below 
 #ifndef RTX_WAVES_LANES
 #define RTX_WAVES_LANES 5
 #endif
+#ifdef RTX_WAVE_CLOCK
+constexpr unsigned kWaveClockCap = 1u << 17;
+__device__ unsigned long long g_wclk[3 * kWaveClockCap];
+__device__ unsigned int g_wclk_n;
+#endif
 template <bool EX = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_LANES))) void k_closest_lanes(SceneDev S, LevelDev L, const int* nrays, int split16, int split4)
 {
@@ -1261,6 +1266,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RTX_WAVE
     Exec exs;
     Exec* ex = EX ? &exs : nullptr;
     ex_zero(ex);
+#ifdef RTX_WAVE_CLOCK
+    // diagnosis build (tools/dbg/wave_clock.py): every wave that traces rays leaves { rays of the launch, start, end } in 10 ns ticks
+    struct WaveClock {
+        unsigned long long t0; int n; bool on;
+        __device__ ~WaveClock()
+        {
+            if (!on || (threadIdx.x & 63) != 0) return;
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned slot = atomicAdd(&g_wclk_n, 1u);
+            if (slot < kWaveClockCap) { g_wclk[3 * slot] = (unsigned long long)n; g_wclk[3 * slot + 1] = t0; g_wclk[3 * slot + 2] = t1; }
+        }
+    } wc{__builtin_amdgcn_s_memrealtime(), n, false};
+    {
+        const int per = (n <= split4) ? 16 : (n <= split16) ? 64 : kBlock;
+        wc.on = (long long)blockIdx.x * per + (long long)w * (per / 4) < n;
+    }
+#endif
     if (n <= split4) {
         if (blockIdx.x * 16 >= n) return;  // block-uniform
         closest_pool<4>(S, L, n, blockIdx.x * 16 + w * 4, pool[w], ex);
