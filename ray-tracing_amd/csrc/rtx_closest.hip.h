@@ -852,8 +852,19 @@ __device__ __forceinline__ void closest_pool(const SceneDev& S, const LevelDev& 
     // t == nearest with a lower index, an affine entry of the staircase is killed by a plain sphere at t <= its own; so
     // L = max(nearest, the live entries' t).  L only falls as hits arrive, a stale value in LDS is a larger one.
     const float cull_abs = 1e-5f * S.guard;
+    // The ray's own parent first: a ray that left a PLAIN sphere (LevelDev::src) -- refracted into it, or reflected inside it -- hits
+    // that sphere again a chord away, and the traversal will find that hit when it reaches the sphere's cluster; knowing its t now
+    // bounds the nearest hit from the start (it is the same test on the same operands, so the same t), and phase 1 culls beyond it
+    // from its first step.  Not a hit yet: LexAcc takes it in phase 1 like any other (plain spheres must not act before the affine
+    // spheres' hits are in).  Rays that left convex spheres outwards miss it: one exact test spent.
+    float tself = kMaxT;
+    if (lane < R && live && !abn) {
+        const int ks = L.src[i];
+        float ts = 0.0f;
+        if (ks >= 0 && exact_hit(S, ks, o, d, nd, ts, ex) == 1 && ts < kMaxT) tself = ts;
+    }
     auto far_limit = [&]() {
-        float lim = h.nearest;
+        float lim = fminf(h.nearest, tself);
 #pragma unroll
         for (int e = 0; e < kAffList; e++) lim = (h.ak[e] >= 0) ? fmaxf(lim, h.at[e]) : lim;
         return __builtin_fmaf(lim, 1.015625f, cull_abs);

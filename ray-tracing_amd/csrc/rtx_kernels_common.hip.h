@@ -73,6 +73,7 @@ struct LevelDev {
     float *n_nx, *n_ny, *n_nz;           // shading normal (after the :458-461 flip)
     float *n_px, *n_py, *n_pz;           // intpoint
     int *n_crefl, *n_crefr;              // child ray slots in the next level, -1 = none
+    int* src;                            // per RAY (generations >= 1): the plain sphere its parent hit left, -1 = none (k_closest_lanes: far limit)
     float* n_fres;                       // fresnel (:465)
     unsigned char* lit;                  // [nl*cap] 1 = light reaches the hit (not in shadow)
 };

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
     }
     F3 o = f3(0, 0, 0), d = o, normal = o, ip = o, rd = o;
     float fres = 0.0f, fratio = 0.0f, eta = 1.0f;
+    int srcp = -1;  // a PLAIN sphere: its children are tested against it first (LevelDev::src)
     if (hit) {
         o = f3(L.ox[i], L.oy[i], L.oz[i]);
         d = f3(L.dx[i], L.dy[i], L.dz[i]);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         if (is_sphere) {
             const float4 sh = S.sph_hot[prim];  // { centre, r * r }
             const bool sxf = S.sph_xf[prim] != 0;
+            if (!sxf) srcp = prim;
             // recompute the winner's object-space normal (:229-231, :395-398)
             F3 to = o, td = d;
             if (sxf) { const rtx_xmatrix& im = S.sph_im[prim]; to = inv_apply(o, im); td = inv_apply(d, im); }
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         r = normalized(r);
         N.ox[crefl] = ip.x + normal.x * kBias; N.oy[crefl] = ip.y + normal.y * kBias; N.oz[crefl] = ip.z + normal.z * kBias;
         N.dx[crefl] = r.x; N.dy[crefl] = r.y; N.dz[crefl] = r.z;
+        N.src[crefl] = srcp;
     }
     if (want_refr) {  // :476-488
         float raydotn = fratio;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_setup(SceneDev S, LevelDev L, LevelDe
         r = normalized(r);
         N.ox[crefr] = ip.x - normal.x * kBias; N.oy[crefr] = ip.y - normal.y * kBias; N.oz[crefr] = ip.z - normal.z * kBias;
         N.dx[crefr] = r.x; N.dy[crefr] = r.y; N.dz[crefr] = r.z;
+        N.src[crefr] = srcp;
     }
 }
 
