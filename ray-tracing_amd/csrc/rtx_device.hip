@@ -793,7 +793,7 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
         double tot = 0;
         for (int k = 0; k < levels; k++) {
             const double cap = (double)cp.cap[k];
-            tot += 19.0 * al(cap * 4.0) + (k ? al(cap * 12.0) : 0.0) + (with_lit ? al(cap * (double)nl1) : 0.0);
+            tot += (k ? 19.0 : 18.0) * al(cap * 4.0) + (k ? al(cap * 12.0) : 0.0) + (with_lit ? al(cap * (double)nl1) : 0.0);  // (LevelDev::src: generations >= 1)
         }
         return tot;
     };
@@ -826,9 +826,10 @@ static int context_create_impl(const rtx_scene* scene, const rtx_params* params,
             float** fl[] = {&L.ox, &L.oy, &L.oz, &L.dx, &L.dy, &L.dz, &L.t, &L.n_nx, &L.n_ny, &L.n_nz, &L.n_px, &L.n_py, &L.n_pz, &L.n_fres};
             for (float** f : fl)
                 if ((rc = c->dalloc(f, cap))) return rc;
-            int** il[] = {&L.prim, &L.n_ray, &L.n_crefl, &L.n_crefr, &L.src};
+            int** il[] = {&L.prim, &L.n_ray, &L.n_crefl, &L.n_crefr};
             for (int** f : il)
                 if ((rc = c->dalloc(f, cap))) return rc;
+            if (k > 0 && (rc = c->dalloc(&L.src, cap))) return rc;  // (primary rays have no parent; only k_closest_lanes reads it)
             if (k == 0) L.val = nullptr;  // level-0 colours are written straight into the float image
             else if ((rc = c->dalloc(&L.val, cap * 3))) return rc;
             if (with_lit && (rc = c->dalloc(&L.lit, cap * nl1))) return rc;
