@@ -49,12 +49,13 @@ SCENES = {
     "lights_in": lambda p: G.write_scene(p, 5000, 5000, [(x, y, z, .1, .1, .1) for x in (-20.0, 20.0) for y in (-10.0, 10.0) for z in (-40.0, -90.0)]),
     "few": lambda p: G.write_scene(p, 6, 6, L4, radius=(3.0, 8.0), edge=20.0, box=(20.0, 12.0), zfar=-60.0),
     "s50k": lambda p: G.write_scene(p, 50000, 0, L4, radius=(0.1, 0.5)),
+    "m1": lambda p: G.write_scene(p, 500000, 500000, L4, radius=(0.05, 0.2), edge=0.4),                              # a million primitives (not in the default list)
     "mixed_sizes": lambda p: (G.write_scene(p, 5000, 5000, L4), append(p, ["sphere 0 0 -70 18  1 1 1  .8 .8 .8  .4 .4 .4  .5 0 1.2 0 8",
                                                                            "sphere 25 5 -50 9  1 1 1  .8 .8 .8  .4 .4 .4  .5 .5 1.2 0 8"])),
 }
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(SCENES)
+    names = sys.argv[1:] or [n for n in SCENES if n != "m1"]
     bad = 0
     for name in names:
         p = os.path.join(tempfile.gettempdir(), "survey_%s.txt" % name)
