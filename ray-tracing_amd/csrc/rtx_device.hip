@@ -1312,6 +1312,18 @@ struct Hash128 {
     {
         const unsigned char* q = static_cast<const unsigned char*>(p);
         word(n);
+        if (n >= 256) {
+            // four independent lanes over 32-byte blocks (the two multiply chains of word() are latency-bound: C4's 1.2 MB of
+            // records took 0.3 ms of a 3.9 ms call), folded into the state in lane order
+            Hash128 l[4];
+            for (int k = 0; k < 4; k++) { l[k].a ^= (uint64_t)(k + 1) * 0x9e3779b97f4a7c15ull; l[k].b += (uint64_t)(k + 1) * 0xc2b2ae3d27d4eb4full; }
+            for (; n >= 32; n -= 32, q += 32) {
+                uint64_t w[4];
+                std::memcpy(w, q, 32);
+                l[0].word(w[0]); l[1].word(w[1]); l[2].word(w[2]); l[3].word(w[3]);
+            }
+            for (int k = 0; k < 4; k++) { word(l[k].a); word(l[k].b); }
+        }
         for (; n >= 8; n -= 8, q += 8) { uint64_t w; std::memcpy(&w, q, 8); word(w); }
         if (n) { uint64_t w = 0; std::memcpy(&w, q, n); word(w); }
     }
