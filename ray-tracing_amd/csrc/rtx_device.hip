@@ -1249,8 +1249,12 @@ static int context_stats_impl(rtx_context* c, rtx_stats* s)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->last_stream));
     std::memset(s, 0, sizeof *s);
-    std::vector<unsigned long long> t(2 * c->levels);
+    // frame totals, test counters, packet statistics and executed-work counters are ONE block (context_create_impl): one copy
+    std::vector<unsigned long long> t((size_t)2 * c->levels + 16 + 3 * EX_KINDS);
     HIPCHK(hipMemcpy(t.data(), c->d_totals, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long* const h_tests = t.data() + (c->d_tests - c->d_totals);
+    const unsigned long long* const h_pstat = t.data() + (c->d_pstat - c->d_totals);
+    const unsigned long long* const h_exec = t.data() + (c->S.exec - c->d_totals);
     uint64_t nprims = (uint64_t)c->S.ns + c->S.nt;
     for (int k = 0; k < c->levels; k++) {
         s->rays_level[k] = t[k];
@@ -1272,17 +1276,12 @@ static int context_stats_impl(rtx_context* c, rtx_stats* s)
     float ms = 0;
     if (c->ev0 && c->ev1) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));  // arena mode keeps no events: 0
     s->ms_total = ms;
-    unsigned long long tk[8];
-    HIPCHK(hipMemcpy(tk, c->d_pstat, sizeof tk, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; k++) s->packet_stats[k] = tk[k];
-    HIPCHK(hipMemcpy(tk, c->d_tests, sizeof tk, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = tk[k]; s->tests_shadow_kind[k] = tk[4 + k]; }
+    for (int k = 0; k < 8; k++) s->packet_stats[k] = h_pstat[k];
+    for (int k = 0; k < 4; k++) { s->tests_closest_kind[k] = h_tests[k]; s->tests_shadow_kind[k] = h_tests[4 + k]; }
     {
         static_assert(EX_KINDS <= RTX_EXEC_KINDS, "rtx_stats.exec_counts holds every kind");
-        unsigned long long ex[3 * EX_KINDS];
-        HIPCHK(hipMemcpy(ex, c->S.exec, sizeof ex, hipMemcpyDeviceToHost));
         for (int kc = 0; kc < 3; kc++)
-            for (int k = 0; k < EX_KINDS; k++) s->exec_counts[kc][k] = ex[kc * EX_KINDS + k];
+            for (int k = 0; k < EX_KINDS; k++) s->exec_counts[kc][k] = h_exec[kc * EX_KINDS + k];
     }
     for (size_t e = 0; e < c->kev_kind.size(); e++) {
         float m = 0;
