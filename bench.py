@@ -235,6 +235,11 @@ def parse_args(argv=None):
     ap.add_argument("--band-rows", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-count", action="store_true", help="skip the untimed counting / serial-timing frames")
+    ap.add_argument("--in-process", action="store_true",
+                    help="time the C-ABI's own multi-GPU form from ONE process: rtx_render_rgb8(..., ngpus = --gpus), one context and "
+                         "one host thread per device, RCCL gather behind the C-ABI, the frame returned in HOST memory (so the value "
+                         "includes that copy: not the headline).  Fewer visible devices than --gpus: every rank on device 0 "
+                         "(RTX_F_MULTI_ON_ONE_DEVICE), flagged in the line")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: also the timed frames run RTX_F_SERIAL (one stream, kernels do not overlap), so a "
                          "rocprofv3 --kernel-trace of this command sees only non-overlapped launches; the value is NOT the headline")
@@ -267,8 +272,79 @@ def launch_plan(gpus, env, argv):
     return "run", None
 
 
+def in_process(args):
+    """--in-process: the C++ multi-GPU path is the one timed.  One process, no torch: K calls of
+    rtx_render_rgb8(scene, params, ngpus = N, host buffer) against the library's resident multi-device cache (contexts, streams,
+    communicators, gather and staging buffers kept between calls), wall clock around them."""
+    import ctypes as C
+    import numpy as np
+    import rtxamd as rt
+    F = rt.host
+    ndev = F.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    wl = rt.scenegen.WORKLOADS[args.workload]
+    W, H, md, N = args.width or wl["width"], args.height or wl["height"], wl["max_depth"], args.gpus
+    scene_path = os.path.join(tempfile.gettempdir(), "rtx_bench_%s_%d.txt" % (args.workload, os.getpid()))
+    wl["writer"](scene_path)
+    scene = rt.load_scene(scene_path)
+    emulated = N > 1 and ndev < N
+    p = rt.Params.make(W, H, md, band_rows=args.band_rows if N > 1 else 0, flags=F.F_MULTI_ON_ONE_DEVICE if emulated else 0)
+    out = np.zeros((H, W, 3), dtype=np.uint8)   # allocated (and touched) once: the calls below copy into it
+    st = F.Stats()
+    lib = F.lib()
+
+    def call():
+        rc = lib.rtx_render_rgb8(scene.ptr, C.byref(p), N, out.ctypes.data, C.byref(st))
+        if rc != 0:
+            raise SystemExit("rtx_render_rgb8(ngpus=%d): %s (%s)" % (N, lib.rtx_strerror(rc).decode(), lib.rtx_last_hip_error().decode()))
+
+    call()   # creates the contexts (and, for N > 1 on N devices, the RCCL communicators)
+    for _ in range(args.warmup):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    dt = time.perf_counter() - t0
+    F.release_cached_context()
+    one, st1 = rt.render_rgb8(scene, rt.Params.make(W, H, md))   # the same frame on one device: its rays, counted once; and the check
+    F.release_cached_context()
+    if not np.array_equal(one, out):
+        raise SystemExit("bench.py --in-process: the %d-device frame differs from the one-device frame" % N)
+    rays = float(st1.rays_primary + st1.rays_secondary + st1.rays_shadow)
+    print(json.dumps({
+        "metric": {"c4": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5",
+                   "c4r": "Mrays/sec (primary+secondary+shadow rays traced) at 4K depth 5, 5% refractive variant",
+                   "c5": "Mrays/sec (primary+secondary+shadow rays traced) at 8K depth 8"}[args.workload],
+        "value": rays * args.steps / dt / 1e6, "unit": "Mrays/s",
+        "value_primary_secondary": float(st1.rays_primary + st1.rays_secondary) * args.steps / dt / 1e6,
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "includes_host_copy": True, "emulated_on_one_device": emulated,
+        "config": {"workload": wl["name"] if not (args.width or args.height) else wl["name"] + " [resized %dx%d]" % (W, H),
+                   "width": W, "height": H, "max_depth": md, "spheres": scene.view.nspheres, "triangles": scene.view.ntriangles,
+                   "lights": scene.view.nlights,
+                   "parallelism": ("in-process C-ABI call, rtx_render_rgb8(ngpus=%d): scanline bands of %d rows round-robin over the devices, "
+                                   "one context and host thread per device, %s, one copy of the frame to the host per call"
+                                   % (N, args.band_rows, "device-to-device copies on ONE device in place of the RCCL gather (emulation)" if emulated
+                                      else "RCCL gather of rgb8 into device 0" if N > 1 else "no gather")),
+                   "rays_per_frame": {"primary": float(st1.rays_primary), "secondary": float(st1.rays_secondary), "shadow": float(st1.rays_shadow)}},
+        "roofline": None, "cpu_baseline": None,
+        "note": "wall clock around K one-shot calls that return the frame in HOST memory (PCIe-inclusive): never the headline value; "
+                "the headline is the default mode's resident render, roofline and cpu_baseline are reported there"}), flush=True)
+    scene.close()
+    try:
+        os.remove(scene_path)
+    except OSError:
+        pass
+
+
 def main():
     args = parse_args()
+    if args.in_process:
+        return in_process(args)
     what, arg = launch_plan(args.gpus, os.environ, sys.argv[1:])
     if what == "error":
         raise SystemExit("bench.py: " + arg)

@@ -97,6 +97,20 @@ def test_render_into_a_device_buffer(rt, gpu):
         hip.hipFree(buf)
 
 
+def test_bench_in_process_mode(gpu):
+    """`bench.py --in-process --gpus 2`: the C++ multi-GPU path (rtx_render_rgb8 with ngpus = 2, resident between calls) timed from
+    one process; on a one-GPU box both ranks run on device 0 and the line says so.  The mode itself checks the frame against the
+    one-device frame byte for byte and exits non-zero if they differ."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--width", "640", "--height", "360"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["includes_host_copy"] is True and line["value"] > 0
+    assert line["config"]["rays_per_frame"]["primary"] == 640 * 360
+    assert "rtx_render_rgb8(ngpus=2)" in line["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("ngpus,band", [(2, 0), (3, 7)])
 def test_in_process_multi_gpu_equals_one_device(rt, gpu, ngpus, band):
     """rtx_render_rgb8(..., ngpus > 1), the CLI's --gpus: one context per device, bands rendered into their send buffers,

@@ -110,7 +110,10 @@ def test_bench_launcher_honours_gpus():
     assert bench.launch_plan(1, {"WORLD_SIZE": "2"}, [])[0] == "error"
     assert bench.launch_plan(0, {}, [])[0] == "error"
     a = bench.parse_args(["--gpus", "2", "--workload", "c5"])
-    assert a.gpus == 2 and a.workload == "c5" and a.steps == 5
+    assert a.gpus == 2 and a.workload == "c5" and a.steps == 5 and not a.in_process
+    # --in-process: ONE process times the C-ABI's own multi-GPU call; nothing is spawned (main() branches before launch_plan)
+    a = bench.parse_args(["--in-process", "--gpus", "8"])
+    assert a.in_process and a.gpus == 8
 
 
 def test_legacy_grammar_loader_reads_the_bundled_scenes_as_written(rt):
